@@ -1,0 +1,150 @@
+/*
+ * nmx.h — C ABI of libnmx_hip.so: the MI355X (gfx950) implementation of nm-vllm's quantized-linear +
+ * paged-attention + KV-cache hot path.
+ *
+ * This is the drop-in boundary. Every entry point replaces one op of the reference's native extension
+ * (`vllm._C`; schemas in csrc/torch_bindings.cpp:18-295, C++ signatures in csrc/ops.h and csrc/cache.h,
+ * Python callers in vllm/_custom_ops.py). No torch types cross this ABI: plain device pointers, sizes,
+ * strides (in elements unless stated), scalar parameters and a HIP stream. All functions only ENQUEUE work on
+ * `stream` (no host synchronisation, no allocation) unless stated, so they are hipGraph-capturable.
+ *
+ * Error model: return 0 on success, a negative NMX_ERR_* code otherwise; `nmx_last_error()` returns a
+ * thread-local message. The Python binding raises RuntimeError with that message, mirroring the reference where
+ * every argument violation is a TORCH_CHECK -> RuntimeError (e.g. csrc/quantization/gptq_marlin/gptq_marlin.cu:1741-1843).
+ *
+ * Paths in comments are relative to the reference root (neuralmagic/nm-vllm @ 2025-01-17).
+ */
+#ifndef NMX_H_
+#define NMX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nmx_stream_t; /* hipStream_t */
+
+/* scalar dtypes of activations / outputs / unquantised KV cache */
+enum { NMX_F32 = 0, NMX_F16 = 1, NMX_BF16 = 2 };
+/* KV-cache storage: "auto" (= scalar dtype), "fp8"/"fp8_e4m3" (OCP e4m3fn), "fp8_e5m2" */
+enum { NMX_KV_AUTO = 0, NMX_KV_FP8_E4M3 = 1, NMX_KV_FP8_E5M2 = 2 };
+/* memcpy direction for nmx_swap_blocks */
+enum { NMX_COPY_D2D = 0, NMX_COPY_D2H = 1, NMX_COPY_H2D = 2 };
+
+enum {
+  NMX_OK = 0,
+  NMX_ERR_INVALID_ARG = -1, /* shape / size / alignment check failed (reference: TORCH_CHECK) */
+  NMX_ERR_UNSUPPORTED = -2, /* unsupported head size / block size / dtype (reference: TORCH_CHECK(false, "Unsupported ...")) */
+  NMX_ERR_HIP = -3          /* a HIP runtime call failed */
+};
+
+const char* nmx_last_error(void);
+/* library version / build info string, e.g. "nmx 0.1 gfx950" */
+const char* nmx_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Paged attention (decode). Replaces paged_attention_v1 / paged_attention_v2
+ * (csrc/attention/attention_kernels.cu:805-826, :966-990; schema csrc/torch_bindings.cpp:23-46).
+ *   out          [num_seqs, num_heads, head_size]           scalar dtype
+ *   query        [num_seqs, num_heads, head_size], row stride q_stride (elements)
+ *   key_cache    [num_blocks, num_kv_heads, head_size/x, block_size, x],  x = 16 / sizeof(cache element)
+ *   value_cache  [num_blocks, num_kv_heads, head_size, block_size]
+ *   block_tables [num_seqs, max_num_blocks_per_seq] int32, seq_lens [num_seqs] int32
+ *   alibi_slopes [num_heads] fp32 or NULL
+ * head_size in {64,80,96,112,128,192,256}, block_size in {8,16,32}; anything else -> NMX_ERR_UNSUPPORTED.
+ * Block-sparse parameters are active iff bs_vert_stride > 1 (attention_kernels.cu:822).
+ * v2 partitions the sequence in 512-token partitions; tmp_out [S,H,P,D] scalar, exp_sums/max_logits [S,H,P] fp32,
+ * P = ceil(max_seq_len / 512) (attention_kernels.cu:885).
+ * ---------------------------------------------------------------------------------------------------------- */
+int nmx_paged_attention_v1(void* out, const void* query, const void* key_cache, const void* value_cache,
+                           int num_seqs, int num_heads, int num_kv_heads, int head_size, int block_size,
+                           int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                           const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                           int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale,
+                           int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
+                           int bs_head_sliding_step, nmx_stream_t stream);
+
+int nmx_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+                           const void* key_cache, const void* value_cache, int num_seqs, int num_heads,
+                           int num_kv_heads, int head_size, int block_size, int64_t q_stride,
+                           int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                           const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                           int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale,
+                           int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
+                           int bs_head_sliding_step, nmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * KV-cache ops. Replace csrc/cache_kernels.cu (schema csrc/torch_bindings.cpp:207-244, csrc/cache.h:8-32).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* reshape_and_cache (cache_kernels.cu:253-278). key/value [num_tokens, num_heads, head_size] with row strides in
+ * elements; slot_mapping [num_tokens] int64, negative = padding token (skipped). fp8: stores fp8(val / kv_scale). */
+int nmx_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
+                          const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size, int block_size,
+                          int x, int64_t key_stride, int64_t value_stride, int dtype, int kv_dtype, float kv_scale,
+                          nmx_stream_t stream);
+
+/* reshape_and_cache_flash (cache_kernels.cu:280-314): caches are [num_blocks, block_size, num_heads, head_size]. */
+int nmx_reshape_and_cache_flash(const void* key, const void* value, void* k_cache, void* v_cache,
+                                const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+                                int block_size, int64_t block_stride, int64_t key_stride, int64_t value_stride,
+                                int elem_size, nmx_stream_t stream);
+
+/* copy_blocks (cache_kernels.cu:101-148). key_cache_ptrs / value_cache_ptrs: DEVICE arrays of num_layers base
+ * pointers; block_mapping: DEVICE [num_pairs, 2] int64 (src, dst); block_bytes = bytes of one block of one layer. */
+int nmx_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs, const int64_t* block_mapping,
+                    int num_layers, int num_pairs, int64_t block_bytes, nmx_stream_t stream);
+
+/* swap_blocks (cache_kernels.cu:24-63). block_mapping: HOST [num_pairs, 2] int64. One async copy per pair. */
+int nmx_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_host, int num_pairs,
+                    int64_t block_bytes, int copy_kind, nmx_stream_t stream);
+
+/* convert_fp8 (cache_kernels.cu:339-389). to_fp8 != 0: dst u8 = fp8(src / scale), src has `dtype`;
+ * else dst (`dtype`) = float(fp8 src) * scale. */
+int nmx_convert_fp8(void* dst, const void* src, int64_t numel, float scale, int dtype, int kv_dtype, int to_fp8,
+                    nmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Marlin-format W4A16 / W8A16 GEMMs.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* gptq_marlin_repack (csrc/quantization/gptq_marlin/gptq_marlin_repack.cu:276-348).
+ * b_q_weight [size_k / pack, size_n] int32 (GPTQ) -> out [size_k / 16, size_n * 16 / pack] int32 (Marlin).
+ * perm [size_k] int32 row gather (act-order) or NULL. Bit-exact with the reference. */
+int nmx_gptq_marlin_repack(const int32_t* b_q_weight, const int32_t* perm, int32_t* out, int size_k, int size_n,
+                           int num_bits, nmx_stream_t stream);
+
+/* Bytes of device scratch the Marlin-family GEMMs need for (size_m, size_n, size_k): split-K partial sums and the
+ * act-order column-permuted copy of A. The caller owns the scratch (allocated once, outside graph capture). */
+int64_t nmx_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k);
+
+/* gptq_marlin_gemm (csrc/quantization/gptq_marlin/gptq_marlin.cu:1735-1868).
+ * c [size_m, size_n] = a [size_m, size_k] * dequant(b_q_weight), W[k,n] = (q - 2^(bits-1)) * s[g(k), n].
+ * b_scales [num_groups, size_n] (Marlin-permuted, scalar dtype). g_idx/perm: [size_k] int32 or NULL (both).
+ * workspace_numel is only validated (>= size_n / 64 * 16, gptq_marlin.cu:1833-1843); the lock words are not used. */
+int nmx_gptq_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, const int32_t* g_idx,
+                         const int32_t* perm, void* c, int64_t workspace_numel, void* scratch,
+                         int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits, int num_groups,
+                         int is_k_full, int dtype, nmx_stream_t stream);
+
+/* marlin_gemm (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136): int4, fp16, groups of 128 or
+ * channel-wise, weights Marlin-packed in the checkpoint. */
+int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,
+                    int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int size_m, int size_n,
+                    int size_k, int num_groups, nmx_stream_t stream);
+
+/* fp8_marlin_gemm (csrc/quantization/fp8/fp8_marlin.cu:1212-1308): W8A16, weight bytes are e4m3fn, channel-wise
+ * scales [1, size_n] (Marlin single-permuted). */
+int nmx_fp8_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,
+                        int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int num_bits, int size_m,
+                        int size_n, int size_k, int dtype, nmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Device utilities (csrc/cuda_utils_kernels.cu).
+ * ---------------------------------------------------------------------------------------------------------- */
+int nmx_get_max_shared_memory_per_block_device_attribute(int device, int* value);
+int nmx_get_device_attribute(int attribute, int device, int* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMX_H_ */

@@ -1,0 +1,422 @@
+"""Drop-in mirror of the reference's ``vllm/_custom_ops.py`` for the hot path, backed by ``libnmx_hip.so``.
+
+Same function names, argument order and error behaviour (RuntimeError on argument violations) as
+``vllm/_custom_ops.py:73-421`` of the reference. Each wrapper only extracts raw device pointers / sizes /
+strides and the current HIP stream, then calls the C-ABI (``include/nmx.h``); nothing here computes on the
+host, and there is no fallback path.
+"""
+import ctypes
+from typing import List, Optional, Tuple, Type
+
+import torch
+
+from . import _lib
+
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f = ctypes.c_float
+c_vp = ctypes.c_void_p
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"Unsupported dtype: {t.dtype}") from None
+
+
+def _kv(kv_cache_dtype: str) -> int:
+    # csrc/quantization/fp8/nvidia/quant_utils.cuh:529-566 (DISPATCH_BY_KV_CACHE_DTYPE)
+    if kv_cache_dtype == "auto":
+        return 0
+    if kv_cache_dtype in ("fp8", "fp8_e4m3"):
+        return 1
+    if kv_cache_dtype == "fp8_e5m2":
+        return 2
+    raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+
+
+def _p(t: Optional[torch.Tensor]) -> c_vp:
+    return c_vp(0) if t is None else c_vp(t.data_ptr())
+
+
+def _dev(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError("expected a GPU (HIP) tensor")
+
+
+def _stream(t: torch.Tensor) -> c_vp:
+    return c_vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def is_custom_op_supported(op_name: str) -> bool:
+    name = op_name.split("::")[-1]
+    return name in globals() and callable(globals()[name])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scratch for split-K partial sums (owned here, allocated outside graph capture, reused by every call)
+# ---------------------------------------------------------------------------------------------------------
+_scratch = {}
+
+
+def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            if buf is None:
+                raise RuntimeError("nmx: GEMM scratch must be allocated before graph capture "
+                                   "(run one eager call first)")
+            return buf  # the C side degrades to fewer K-splits that fit
+        nbytes = max(nbytes, 64 << 20)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------------------------------------
+# paged attention (vllm/_custom_ops.py:73-129)
+# ---------------------------------------------------------------------------------------------------------
+def _attn_common(fn, head_args, query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                 block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
+                 blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                 blocksparse_head_sliding_step):
+    _dev(query)
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("block_tables and seq_lens must be int32")
+    num_seqs, num_heads, head_size = query.shape
+    if query.stride(1) != head_size or query.stride(2) != 1:
+        raise RuntimeError("query must be contiguous in its last two dimensions")
+    _lib.check(
+        fn(*head_args, _p(query), _p(key_cache), _p(value_cache), c_int(num_seqs), c_int(num_heads),
+           c_int(num_kv_heads), c_int(head_size), c_int(block_size), c_i64(query.stride(0)),
+           c_i64(key_cache.stride(0)), c_i64(key_cache.stride(1)), c_f(scale), _p(block_tables),
+           c_int(block_tables.size(1)), _p(seq_lens), c_int(max_seq_len), _p(alibi_slopes), c_int(_dt(query)),
+           c_int(_kv(kv_cache_dtype)), c_f(kv_scale), c_int(tp_rank), c_int(blocksparse_local_blocks),
+           c_int(blocksparse_vert_stride), c_int(blocksparse_block_size), c_int(blocksparse_head_sliding_step),
+           _stream(query)))
+
+
+def paged_attention_v1(
+    out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 0,
+    blocksparse_block_size: int = 64,
+    blocksparse_head_sliding_step: int = 0,
+) -> None:
+    _attn_common(_lib.lib().nmx_paged_attention_v1, (_p(out), ), query, key_cache, value_cache, num_kv_heads, scale,
+                 block_tables, seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
+                 blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                 blocksparse_head_sliding_step)
+
+
+def paged_attention_v2(
+    out: torch.Tensor,
+    exp_sum: torch.Tensor,
+    max_logits: torch.Tensor,
+    tmp_out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 0,
+    blocksparse_block_size: int = 64,
+    blocksparse_head_sliding_step: int = 0,
+) -> None:
+    _attn_common(_lib.lib().nmx_paged_attention_v2, (_p(out), _p(exp_sum), _p(max_logits), _p(tmp_out)), query,
+                 key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                 alibi_slopes, kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
+                 blocksparse_block_size, blocksparse_head_sliding_step)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# KV-cache ops (vllm/_custom_ops.py:370-412)
+# ---------------------------------------------------------------------------------------------------------
+def reshape_and_cache(
+    key: torch.Tensor,
+    value: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    slot_mapping: torch.Tensor,
+    kv_cache_dtype: str,
+    kv_scale: float,
+) -> None:
+    _dev(key)
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("slot_mapping must be int64")
+    num_tokens, num_heads, head_size = key.shape
+    _lib.check(_lib.lib().nmx_reshape_and_cache(
+        _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping), c_int(num_tokens), c_int(num_heads),
+        c_int(head_size), c_int(key_cache.size(3)), c_int(key_cache.size(4)), c_i64(key.stride(0)),
+        c_i64(value.stride(0)), c_int(_dt(key)), c_int(_kv(kv_cache_dtype)), c_f(kv_scale), _stream(key)))
+
+
+def reshape_and_cache_flash(
+    key: torch.Tensor,
+    value: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    slot_mapping: torch.Tensor,
+    kv_cache_dtype: str,
+) -> None:
+    _dev(key)
+    if kv_cache_dtype != "auto":  # csrc/cache_kernels.cu:288-291
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+    if key_cache.stride(0) != value_cache.stride(0):
+        raise RuntimeError("k_cache.stride(0) == v_cache.stride(0) must hold")
+    num_tokens, num_heads, head_size = key.shape
+    _lib.check(_lib.lib().nmx_reshape_and_cache_flash(
+        _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping), c_int(num_tokens), c_int(num_heads),
+        c_int(head_size), c_int(key_cache.size(1)), c_i64(key_cache.stride(0)), c_i64(key.stride(0)),
+        c_i64(value.stride(0)), c_int(key.element_size()), _stream(key)))
+
+
+_ptr_arrays = {}
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: torch.Tensor) -> None:
+    num_layers = len(key_caches)
+    if num_layers != len(value_caches):
+        raise RuntimeError("key_caches and value_caches must have the same length")
+    if num_layers == 0:
+        return
+    dev = key_caches[0].device
+    _dev(key_caches[0])
+    # device arrays of base pointers; the reference re-uploads them (with a sync) on every call
+    # (csrc/cache_kernels.cu:126-133). KV caches live for the engine's lifetime, so cache the upload.
+    key = (dev.index, tuple(t.data_ptr() for t in key_caches), tuple(t.data_ptr() for t in value_caches))
+    arrs = _ptr_arrays.get(key)
+    if arrs is None:
+        kp = torch.tensor([t.data_ptr() for t in key_caches], dtype=torch.int64).to(dev)
+        vp = torch.tensor([t.data_ptr() for t in value_caches], dtype=torch.int64).to(dev)
+        if len(_ptr_arrays) > 64:
+            _ptr_arrays.clear()
+        arrs = _ptr_arrays[key] = (kp, vp)
+    bm = block_mapping
+    if bm.dtype != torch.int64 or not bm.is_cuda or not bm.is_contiguous():
+        bm = bm.to(device=dev, dtype=torch.int64).contiguous()
+    block_bytes = key_caches[0][0].numel() * key_caches[0].element_size()
+    _lib.check(_lib.lib().nmx_copy_blocks(_p(arrs[0]), _p(arrs[1]), _p(bm), c_int(num_layers), c_int(bm.size(0)),
+                                          c_i64(block_bytes), _stream(key_caches[0])))
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    # csrc/cache_kernels.cu:24-63
+    if src.is_cuda and dst.is_cuda:
+        if src.device != dst.device:
+            raise RuntimeError("src and dst must be on the same GPU")
+        kind = 0
+    elif src.is_cuda and not dst.is_cuda:
+        kind = 1
+    elif not src.is_cuda and dst.is_cuda:
+        kind = 2
+    else:
+        raise RuntimeError("Invalid device combination")
+    if block_mapping.is_cuda:
+        raise RuntimeError("block_mapping must be on CPU")
+    bm = block_mapping.to(torch.int64).contiguous()
+    block_bytes = src.element_size() * src[0].numel()
+    gpu = src if src.is_cuda else dst
+    with torch.cuda.device(gpu.device):
+        _lib.check(_lib.lib().nmx_swap_blocks(_p(src), _p(dst), _p(bm), c_int(bm.size(0)), c_i64(block_bytes),
+                                              c_int(kind), _stream(gpu)))
+
+
+def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0, kv_dtype: str = "fp8") -> None:
+    # csrc/cache_kernels.cu:339-389
+    if not input.is_cuda:
+        raise RuntimeError("src must be on a GPU")
+    if not output.is_cuda:
+        raise RuntimeError("dst must be on a GPU")
+    if input.device != output.device:
+        raise RuntimeError("src and dst must be on the same GPU")
+    kv = _kv(kv_dtype) or 1  # "auto" converts as e4m3 (cache_kernels.cu:353-366)
+    if input.numel() != output.numel():
+        raise RuntimeError("convert_fp8: size mismatch")
+    if output.dtype == torch.uint8 and input.dtype != torch.uint8:
+        _lib.check(_lib.lib().nmx_convert_fp8(_p(output), _p(input), c_i64(input.numel()), c_f(scale),
+                                              c_int(_dt(input)), c_int(kv), c_int(1), _stream(input)))
+    elif input.dtype == torch.uint8:
+        _lib.check(_lib.lib().nmx_convert_fp8(_p(output), _p(input), c_i64(input.numel()), c_f(scale),
+                                              c_int(_dt(output)), c_int(kv), c_int(0), _stream(input)))
+    else:
+        raise RuntimeError("convert_fp8: one side must be uint8 (fp8 storage)")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Marlin family (vllm/_custom_ops.py:200-280)
+# ---------------------------------------------------------------------------------------------------------
+def gptq_marlin_repack(b_q_weight: torch.Tensor, perm: torch.Tensor, size_k: int, size_n: int,
+                       num_bits: int) -> torch.Tensor:
+    # csrc/quantization/gptq_marlin/gptq_marlin_repack.cu:276-348
+    _dev(b_q_weight)
+    if num_bits not in (4, 8):
+        raise RuntimeError(f"num_bits must be 4 or 8. Got = {num_bits}")
+    pack_factor = 32 // num_bits
+    if size_k % 16 != 0:
+        raise RuntimeError(f"size_k = {size_k} is not divisible by tile_k_size = 16")
+    if (size_k // pack_factor) != b_q_weight.size(0):
+        raise RuntimeError(f"Shape mismatch: b_q_weight.size(0) = {b_q_weight.size(0)}, size_k = {size_k}, "
+                           f"pack_factor = {pack_factor}")
+    if b_q_weight.size(1) != size_n:
+        raise RuntimeError(f"b_q_weight.size(1) = {b_q_weight.size(1)} is not size_n = {size_n}")
+    if not b_q_weight.is_contiguous():
+        raise RuntimeError("b_q_weight is not contiguous")
+    if b_q_weight.dtype != torch.int32:
+        raise RuntimeError("b_q_weight type is not kInt")
+    has_perm = perm.numel() != 0
+    if has_perm and (perm.dtype != torch.int32 or not perm.is_cuda or not perm.is_contiguous()):
+        raise RuntimeError("perm must be a contiguous int32 GPU tensor")
+    out = torch.empty((size_k // 16, size_n * 16 // pack_factor), dtype=torch.int32, device=b_q_weight.device)
+    _lib.check(_lib.lib().nmx_gptq_marlin_repack(_p(b_q_weight), _p(perm if has_perm else None), _p(out),
+                                                 c_int(size_k), c_int(size_n), c_int(num_bits),
+                                                 _stream(b_q_weight)))
+    return out
+
+
+def _marlin_scratch(a: torch.Tensor, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    need = _lib.lib().nmx_marlin_gemm_scratch_bytes(c_int(size_m), c_int(size_n), c_int(size_k))
+    return _get_scratch(a.device, int(need))
+
+
+def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor, g_idx: torch.Tensor,
+                     perm: torch.Tensor, workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int,
+                     size_k: int, is_k_full: bool) -> torch.Tensor:
+    # checks mirror csrc/quantization/gptq_marlin/gptq_marlin.cu:1735-1843
+    if num_bits not in (4, 8):
+        raise RuntimeError(f"num_bits must be 4 or 8. Got = {num_bits}")
+    pack_factor = 32 // num_bits
+    if a.size(0) != size_m:
+        raise RuntimeError(f"Shape mismatch: a.size(0) = {a.size(0)}, size_m = {size_m}")
+    if a.size(1) != size_k:
+        raise RuntimeError(f"Shape mismatch: a.size(1) = {a.size(1)}, size_k = {size_k}")
+    if size_k % 16 != 0:
+        raise RuntimeError(f"size_k = {size_k} is not divisible by tile_size = 16")
+    if (size_k // 16) != b_q_weight.size(0):
+        raise RuntimeError(f"Shape mismatch: b_q_weight.size(0) = {b_q_weight.size(0)}, size_k = {size_k}, "
+                           "tile_size = 16")
+    if b_q_weight.size(1) % 16 != 0:
+        raise RuntimeError(f"b_q_weight.size(1) = {b_q_weight.size(1)} is not divisible by tile_size = 16")
+    actual_size_n = (b_q_weight.size(1) // 16) * pack_factor
+    if size_n != actual_size_n:
+        raise RuntimeError(f"size_n = {size_n}, actual_size_n = {actual_size_n}")
+    for name, t in (("A", a), ("b_q_weight", b_q_weight), ("b_scales", b_scales), ("g_idx", g_idx), ("perm", perm)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} is not on GPU")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} is not contiguous")
+    if not ((g_idx.size(0) == 0 and perm.size(0) == 0) or (g_idx.size(0) == size_k and perm.size(0) == size_k)):
+        raise RuntimeError(f"Unexpected g_idx.size(0) = {g_idx.size(0)} and perm.size(0) = {perm.size(0)}, "
+                           f"where size_k = {size_k}")
+    if b_scales.dim() != 2:
+        raise RuntimeError(f"b_scales rank = {b_scales.dim()} is not 2")
+    if b_scales.size(1) != size_n:
+        raise RuntimeError(f"b_scales dim 1 = {b_scales.size(1)} is not size_n = {size_n}")
+    if a.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("gpt_marlin_gemm only supports bfloat16 and float16")
+    if b_scales.dtype != a.dtype:
+        raise RuntimeError("b_scales must have the dtype of a")
+    has_act = g_idx.size(0) != 0
+    if has_act and (g_idx.dtype != torch.int32 or perm.dtype != torch.int32):
+        raise RuntimeError("g_idx and perm must be int32")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    _lib.check(_lib.lib().nmx_gptq_marlin_gemm(
+        _p(a), _p(b_q_weight), _p(b_scales), _p(g_idx if has_act else None), _p(perm if has_act else None), _p(c),
+        c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n), c_int(size_k),
+        c_int(num_bits), c_int(b_scales.size(0)), c_int(int(bool(is_k_full))), c_int(_dt(a)), _stream(a)))
+    return c
+
+
+def marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor, workspace: torch.Tensor,
+                size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    # checks mirror csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1100
+    if a.size(0) != size_m:
+        raise RuntimeError(f"Shape mismatch: a.size(0) = {a.size(0)}, size_m = {size_m}")
+    if a.size(1) != size_k:
+        raise RuntimeError(f"Shape mismatch: a.size(1) = {a.size(1)}, size_k = {size_k}")
+    if size_k % 16 != 0:
+        raise RuntimeError(f"size_k = {size_k} is not divisible by tile_size = 16")
+    if (size_k // 16) != b_q_weight.size(0):
+        raise RuntimeError(f"Shape mismatch: b_q_weight.size(0) = {b_q_weight.size(0)}, size_k = {size_k}, "
+                           "tile_size = 16")
+    if b_scales.size(1) != size_n:
+        raise RuntimeError(f"b_scales.size(1) = {b_scales.size(1)}, size_n = {size_n}")
+    if size_k % b_scales.size(0) != 0:
+        raise RuntimeError(f"size_k = {size_k}, is not divisible by b_scales.size(0) = {b_scales.size(0)}")
+    if a.dtype != torch.float16:
+        raise RuntimeError("marlin_gemm only supports float16")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    _lib.check(_lib.lib().nmx_marlin_gemm(_p(a.contiguous()), _p(b_q_weight), _p(b_scales), _p(c),
+                                          c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()),
+                                          c_int(size_m), c_int(size_n), c_int(size_k), c_int(b_scales.size(0)),
+                                          _stream(a)))
+    return c
+
+
+def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor, workspace: torch.Tensor,
+                    num_bits: int, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    # checks mirror csrc/quantization/fp8/fp8_marlin.cu:1212-1280
+    if num_bits != 8:
+        raise RuntimeError(f"num_bits must be 8 for fp8 marlin. Got = {num_bits}")
+    if a.size(0) != size_m:
+        raise RuntimeError(f"Shape mismatch: a.size(0) = {a.size(0)}, size_m = {size_m}")
+    if a.size(1) != size_k:
+        raise RuntimeError(f"Shape mismatch: a.size(1) = {a.size(1)}, size_k = {size_k}")
+    if (size_k // 16) != b_q_weight.size(0):
+        raise RuntimeError(f"Shape mismatch: b_q_weight.size(0) = {b_q_weight.size(0)}, size_k = {size_k}, "
+                           "tile_size = 16")
+    if b_scales.dim() != 2 or b_scales.size(1) != size_n or b_scales.size(0) != 1:
+        raise RuntimeError(f"b_scales must be [1, {size_n}] (channel-wise only)")
+    if a.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("fp8_marlin_gemm only supports bfloat16 and float16")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    _lib.check(_lib.lib().nmx_fp8_marlin_gemm(_p(a.contiguous()), _p(b_q_weight), _p(b_scales.contiguous()), _p(c),
+                                              c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()),
+                                              c_int(num_bits), c_int(size_m), c_int(size_n), c_int(size_k),
+                                              c_int(_dt(a)), _stream(a)))
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device utilities (vllm/_custom_ops.py:415-422)
+# ---------------------------------------------------------------------------------------------------------
+def get_device_attribute(attribute: int, device: int) -> int:
+    v = c_int(0)
+    _lib.check(_lib.lib().nmx_get_device_attribute(c_int(attribute), c_int(device), ctypes.byref(v)))
+    return v.value
+
+
+def get_max_shared_memory_per_block_device_attribute(device: int) -> int:
+    v = c_int(0)
+    _lib.check(_lib.lib().nmx_get_max_shared_memory_per_block_device_attribute(c_int(device), ctypes.byref(v)))
+    return v.value

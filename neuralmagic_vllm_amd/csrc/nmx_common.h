@@ -1,0 +1,103 @@
+// Common device/host helpers for libnmx_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/nmx.h"
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+void nmx_set_error(const char* fmt, ...);
+
+#define NMX_CHECK(cond, code, ...)  \
+  do {                              \
+    if (!(cond)) {                  \
+      nmx_set_error(__VA_ARGS__);   \
+      return (code);                \
+    }                               \
+  } while (0)
+
+#define NMX_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      nmx_set_error("HIP error %d (%s) at %s:%d", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return NMX_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define NMX_LAUNCH_CHECK() NMX_HIP(hipGetLastError())
+
+// ---- vector types ---------------------------------------------------------------------------------------
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#define NMX_WAVE 64
+
+// ---- scalar conversions (device) ------------------------------------------------------------------------
+template <typename T> struct Scalar;
+template <> struct Scalar<float> {
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Scalar<f16> {
+  static __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+  static __device__ __forceinline__ f16 from_f32(float v) { return (f16)v; }
+};
+template <> struct Scalar<bf16> {
+  static __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+  static __device__ __forceinline__ bf16 from_f32(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+};
+
+// fp8 (OCP) byte -> float
+__device__ __forceinline__ float fp8_e4m3_to_f32(uint8_t v) {
+  return __builtin_amdgcn_cvt_f32_fp8((uint32_t)v, 0);
+}
+__device__ __forceinline__ float fp8_e5m2_to_f32(uint8_t v) {
+  return __builtin_amdgcn_cvt_f32_bf8((uint32_t)v, 0);
+}
+// float -> fp8 byte, round-to-nearest-even, saturating to max finite (reference: __NV_SATFINITE)
+__device__ __forceinline__ uint8_t f32_to_fp8_e4m3_sat(float f) {
+  // v_cvt_pk_fp8_f32 saturates when the FP16_OVFL-independent clamp is applied by us (NaN propagates)
+  f = __builtin_isnan(f) ? f : __builtin_fminf(__builtin_fmaxf(f, -448.0f), 448.0f);
+  return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(f, f, 0, false) & 0xff);
+}
+__device__ __forceinline__ uint8_t f32_to_fp8_e5m2_sat(float f) {
+  f = __builtin_isnan(f) ? f : __builtin_fminf(__builtin_fmaxf(f, -57344.0f), 57344.0f);
+  return (uint8_t)(__builtin_amdgcn_cvt_pk_bf8_f32(f, f, 0, false) & 0xff);
+}
+template <int KV> __device__ __forceinline__ float fp8_to_f32(uint8_t v) {
+  if constexpr (KV == NMX_KV_FP8_E4M3) return fp8_e4m3_to_f32(v);
+  else return fp8_e5m2_to_f32(v);
+}
+template <int KV> __device__ __forceinline__ uint8_t f32_to_fp8_sat(float f) {
+  if constexpr (KV == NMX_KV_FP8_E4M3) return f32_to_fp8_e4m3_sat(f);
+  else return f32_to_fp8_e5m2_sat(f);
+}
+
+// ---- wave-level reductions ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+static inline int nmx_dtype_size(int dt) { return dt == NMX_F32 ? 4 : 2; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,533 @@
+// Paged-attention decode (v1 / v2) for gfx950 — MFMA, wave64, GQA-aware.
+//
+// Replaces csrc/attention/attention_kernels.cu of the reference (paged_attention_v1 :805-826,
+// paged_attention_v2 :966-990, reduce kernel :567-669). Same op semantics; a different algorithm:
+//
+//  * One workgroup per (kv_head, sequence[, 512-token partition]) handles ALL query heads that share the kv head
+//    (the reference launches one block per query head, so a GQA-4 model fetches each KV byte 4 times).
+//  * The KV-cache layout the reference prescribes maps 1:1 onto MFMA 16x16x32 operand fragments:
+//      K cache [.., D/8, BS, 8] (fp16): the 16 B at chunk c, token t ARE the A-fragment of lane (g = c % 4, i = t)
+//      for S^T = K . Q^T, so K goes HBM -> VGPR -> MFMA with one coalesced dwordx4 per lane and no LDS;
+//      V cache [.., D, BS]: the 16 B at row d, tokens 8g..8g+7 ARE the A-fragment of lane (g, i = d % 16) for
+//      O^T = V^T . P^T.
+//    Both products are computed transposed so that the query row sits on lane & 15 for the softmax statistics, the
+//    P fragment and the O accumulator alike: running max / sum / rescale are lane-local.
+//  * P (4 tokens per lane per 16-token sub-tile, C/D layout) is re-shaped into the B-operand layout (8 consecutive
+//    tokens per lane) with two cross-lane swaps (v_permlane32_swap + v_permlane16_swap), no LDS round trip.
+//  * Online softmax over 32-token tiles, fp32 statistics; probabilities are cast to scalar_t before P.V like the
+//    reference (:398-400); the final normaliser is 1 / (sum + 1e-6) (:342, :652).
+//
+// HBM-bound: algorithmic bytes per (sequence, kv head) = 2 * seq_len * D * sizeof(cache element).
+#include <float.h>
+
+#include "nmx_common.h"
+
+namespace {
+
+constexpr int kPartitionSize = 512;  // fixed by the op contract (attention_kernels.cu:847)
+constexpr int kTile = 32;            // tokens per wave iteration
+
+struct AttnParams {
+  void* out;          // v1: [S, H, D]; v2: tmp_out [S, H, P, D]
+  float* exp_sums;    // v2: [S, H, P]
+  float* max_logits;  // v2: [S, H, P]
+  const void* q;
+  const void* k_cache;
+  const void* v_cache;
+  const int32_t* block_tables;
+  const int32_t* seq_lens;
+  const float* alibi_slopes;
+  int64_t q_stride, kv_block_stride, kv_head_stride;
+  float scale, kv_scale;
+  int num_heads, num_kv_heads, q_per_kv, q_tiles;
+  int max_blocks_per_seq, block_size, bs_shift;
+  int partitioned, max_num_partitions;
+  int sparse, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step;
+};
+
+template <typename scalar_t>
+__device__ __forceinline__ f32x4 mfma_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (sizeof(scalar_t) == 2 && __is_same(scalar_t, f16)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+}
+
+template <typename scalar_t>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  union { scalar_t h[2]; uint32_t u; } r;
+  r.h[0] = Scalar<scalar_t>::from_f32(lo);
+  r.h[1] = Scalar<scalar_t>::from_f32(hi);
+  return r.u;
+}
+
+// 8 fp8 bytes (two dwords) -> 8 scalar_t (four dwords): scalar_t(float(fp8) * scale), RNE
+// (reference: csrc/quantization/fp8/nvidia/quant_utils.cuh:293-345)
+template <typename scalar_t, int KV>
+__device__ __forceinline__ u32x4 cvt8_fp8(u32x2 w, float scale) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f32x2 lo, hi;
+    if constexpr (KV == NMX_KV_FP8_E4M3) {
+      lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false);
+      hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+    } else {
+      lo = __builtin_amdgcn_cvt_pk_f32_bf8(w[i], false);
+      hi = __builtin_amdgcn_cvt_pk_f32_bf8(w[i], true);
+    }
+    r[2 * i] = pack2<scalar_t>(lo[0] * scale, lo[1] * scale);
+    r[2 * i + 1] = pack2<scalar_t>(hi[0] * scale, hi[1] * scale);
+  }
+  return r;
+}
+
+// Re-shape P from the MFMA C/D layout into the B-operand layout.
+// In : a = sub-tile 0, b = sub-tile 1; lane (g, q) holds tokens 4g..4g+3 of each (two packed dwords).
+// Out: lane (g, q) holds tokens 8(g&1)..8(g&1)+7 of sub-tile g>>1 (four packed dwords, token order).
+__device__ __forceinline__ u32x4 p_to_operand(u32x2 a, u32x2 b) {
+  u32x4 r;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    // lanes 32-63 of a <-> lanes 0-31 of b
+    auto s1 = __builtin_amdgcn_permlane32_swap(a[d], b[d], false, false);
+    // rows 1,3 of the first <-> rows 0,2 of the second
+    auto s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+    r[d] = s2[0];
+    r[2 + d] = s2[1];
+  }
+  return r;
+}
+
+template <typename scalar_t, int KV, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const AttnParams p) {
+  constexpr int KS = (D + 31) / 32;  // k-steps of the QK^T product
+  constexpr int NT = D / 16;         // 16-wide d tiles of the output
+  constexpr int CHUNKS = D / 8;      // 8-element chunks per head vector
+  constexpr bool FP8 = (KV != NMX_KV_AUTO);
+  using cache_t = typename std::conditional<FP8, uint8_t, scalar_t>::type;
+
+  const int kvh = blockIdx.x / p.q_tiles;
+  const int qt = blockIdx.x % p.q_tiles;
+  const int seq = blockIdx.y;
+  const int part = blockIdx.z;
+  const int seq_len = p.seq_lens[seq];
+
+  int tok_begin = 0, tok_end = seq_len;
+  if (p.partitioned) {
+    tok_begin = part * kPartitionSize;
+    if (tok_begin >= seq_len) return;  // attention_kernels.cu:116-119
+    tok_end = min(seq_len, tok_begin + kPartitionSize);
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const int li = lane & 15;
+
+  const int q_row = qt * 16 + li;
+  const bool q_valid = q_row < p.q_per_kv;
+  const int head = kvh * p.q_per_kv + (q_valid ? q_row : 0);
+
+  // ---- Q fragments (B operand of S^T = K . Q^T): lane (g, q) holds Q[q][32 ks + 8 g .. +7] ----
+  u32x4 qf[KS];
+  {
+    const scalar_t* qp = reinterpret_cast<const scalar_t*>(p.q) + (int64_t)seq * p.q_stride + (int64_t)head * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int chunk = 4 * ks + g;
+      u32x4 v = {0, 0, 0, 0};
+      if (q_valid && chunk < CHUNKS) v = *reinterpret_cast<const u32x4*>(qp + chunk * 8);
+      qf[ks] = v;
+    }
+  }
+
+  const float slope = (p.alibi_slopes != nullptr && q_valid) ? p.alibi_slopes[head] : 0.f;
+  // block-sparse (attention_kernels.cu:209-256)
+  int bs_block_offset = 0, q_bs_block_id = 0;
+  if (p.sparse) {
+    q_bs_block_id = (seq_len - 1) / p.bs_block_size;
+    if (p.bs_head_sliding_step >= 0)
+      bs_block_offset = (p.tp_rank * p.num_heads + head) * p.bs_head_sliding_step + 1;
+    else
+      bs_block_offset = (p.tp_rank * p.num_kv_heads + kvh) * (-p.bs_head_sliding_step) + 1;
+  }
+
+  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  const cache_t* kc = reinterpret_cast<const cache_t*>(p.k_cache) + (int64_t)kvh * p.kv_head_stride;
+  const cache_t* vc = reinterpret_cast<const cache_t*>(p.v_cache) + (int64_t)kvh * p.kv_head_stride;
+  const int BS = p.block_size;
+  const int bs_mask = BS - 1;
+  const int last_tok = seq_len - 1;
+
+  float m_run = -FLT_MAX;
+  float l_part = 0.f;
+  f32x4 o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_tiles = (tok_end - tok_begin + kTile - 1) / kTile;
+  for (int tile = wave; tile < n_tiles; tile += NW) {
+    const int t0 = tok_begin + tile * kTile;
+
+    // ---- K fragments: lane (g, i) <- token t0 + 16u + i, chunk 4 ks + g ----
+    u32x4 kf[2][KS];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int tok = min(t0 + 16 * u + li, last_tok);
+      const int64_t phys = bt[tok >> p.bs_shift];
+      const int off = tok & bs_mask;
+      const cache_t* kb = kc + phys * p.kv_block_stride;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int chunk = 4 * ks + g;
+        u32x4 v = {0, 0, 0, 0};
+        if (chunk < CHUNKS) {
+          if constexpr (!FP8) {
+            v = *reinterpret_cast<const u32x4*>(kb + ((int64_t)chunk * BS + off) * 8);
+          } else {
+            // x = 16: 16-element chunks; this lane's 8 elements are the (chunk & 1) half of chunk >> 1
+            const u32x2 w = *reinterpret_cast<const u32x2*>(kb + ((int64_t)(chunk >> 1) * BS + off) * 16 + 8 * (chunk & 1));
+            v = cvt8_fp8<scalar_t, KV>(w, p.kv_scale);
+          }
+        }
+        kf[u][ks] = v;
+      }
+    }
+
+    // ---- V fragments: lane (g, i) <- row d = 16 nt + i, tokens t0 + 8 g .. + 7 ----
+    u32x4 vf[NT];
+    {
+      const int tokv = t0 + 8 * g;
+      const int tokc = min(tokv, last_tok & ~7);
+      const int64_t phys = bt[tokc >> p.bs_shift];
+      const int off = tokc & bs_mask;
+      const cache_t* vb = vc + phys * p.kv_block_stride + off;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int d = 16 * nt + li;
+        if constexpr (!FP8) {
+          vf[nt] = *reinterpret_cast<const u32x4*>(vb + (int64_t)d * BS);
+        } else {
+          const u32x2 w = *reinterpret_cast<const u32x2*>(vb + (int64_t)d * BS);
+          vf[nt] = cvt8_fp8<scalar_t, KV>(w, p.kv_scale);
+        }
+      }
+      if (t0 + kTile > seq_len) {
+        // zero V for tokens past the end of the sequence: they may hold NaNs (attention_kernels.cu:420-430)
+        const int nvalid = max(0, min(8, seq_len - tokv));
+#pragma unroll
+        for (int dw = 0; dw < 4; ++dw) {
+          const uint32_t keep = (nvalid >= 2 * dw + 2) ? 0xffffffffu : ((nvalid == 2 * dw + 1) ? 0x0000ffffu : 0u);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) vf[nt][dw] &= keep;
+        }
+      }
+    }
+
+    // ---- S^T = K . Q^T : lane (g, q) gets tokens t0 + 16u + 4g + r ----
+    f32x4 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[u] = mfma_16x16x32<scalar_t>(kf[u][ks], qf[ks], s[u]);
+    }
+
+    // ---- logits, mask, online softmax ----
+    bool msk[2][4];
+    float m_tile = -FLT_MAX;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = t0 + 16 * u + 4 * g + r;
+        float v = s[u][r] * p.scale;
+        v += (slope != 0.f) ? slope * (float)(tok - seq_len + 1) : 0.f;
+        bool masked = tok >= seq_len;
+        if (p.sparse) {
+          const int kb_id = ((tok >> p.bs_shift) << p.bs_shift) / p.bs_block_size;
+          const bool is_remote = ((kb_id + bs_block_offset) % p.bs_vert_stride) == 0;
+          const bool is_local = kb_id > q_bs_block_id - p.bs_local_blocks;
+          masked = masked || !(is_remote || is_local);
+        }
+        msk[u][r] = masked;
+        s[u][r] = v;
+        m_tile = masked ? m_tile : fmaxf(m_tile, v);
+      }
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+
+    float psum = 0.f;
+    u32x2 pk[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e[r] = msk[u][r] ? 0.f : __expf(s[u][r] - m_new);
+        psum += e[r];
+      }
+      pk[u][0] = pack2<scalar_t>(e[0], e[1]);
+      pk[u][1] = pack2<scalar_t>(e[2], e[3]);
+    }
+    l_part = l_part * alpha + psum;
+
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+    }
+
+    // ---- O^T += V^T . P^T ----
+    const u32x4 pb = p_to_operand(pk[0], pk[1]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] = mfma_16x16x32<scalar_t>(vf[nt], pb, o[nt]);
+  }
+
+  // ---- combine the NW waves through LDS ----
+  l_part += __shfl_xor(l_part, 16, 64);
+  l_part += __shfl_xor(l_part, 32, 64);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds_m = reinterpret_cast<float*>(smem);          // [NW][16]
+  float* lds_l = lds_m + NW * 16;                          // [NW][16]
+  float* lds_o = lds_l + NW * 16;                          // [NW][16][D]
+  if (g == 0) {
+    lds_m[wave * 16 + li] = m_run;
+    lds_l[wave * 16 + li] = l_part;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    // lane (g, q) holds O[q][16 nt + 4 g + r]
+    *reinterpret_cast<f32x4*>(lds_o + ((int64_t)wave * 16 + li) * D + 16 * nt + 4 * g) = o[nt];
+  }
+  __syncthreads();
+
+  const int t = threadIdx.x;
+  const int cq = t & 15;            // query row within the tile
+  const int cq_row = qt * 16 + cq;
+  if (cq_row >= p.q_per_kv) return;
+  const int chead = kvh * p.q_per_kv + cq_row;
+  float M = -FLT_MAX;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) M = fmaxf(M, lds_m[w * 16 + cq]);
+  float f[NW];
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    f[w] = __expf(lds_m[w * 16 + cq] - M);
+    L += lds_l[w * 16 + cq] * f[w];
+  }
+  const float inv = __fdividef(1.f, L + 1e-6f);
+  scalar_t* outp;
+  if (p.partitioned) {
+    const int64_t pidx = ((int64_t)seq * p.num_heads + chead) * p.max_num_partitions + part;
+    outp = reinterpret_cast<scalar_t*>(p.out) + pidx * D;
+    if ((t >> 4) == 0) {
+      p.max_logits[pidx] = M;
+      p.exp_sums[pidx] = L;
+    }
+  } else {
+    outp = reinterpret_cast<scalar_t*>(p.out) + ((int64_t)seq * p.num_heads + chead) * D;
+  }
+  // thread handles d = 4 * (t >> 4) + {0..3}, stepping by 4 * (NW * 4)
+  for (int d0 = 4 * (t >> 4); d0 < D; d0 += 16 * NW) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + ((int64_t)w * 16 + cq) * D + d0);
+      acc += v * f[w];
+    }
+    acc *= inv;
+    union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
+    *reinterpret_cast<u32x2*>(outp + d0) = r.u;
+  }
+}
+
+// v2 reduce: grid (num_heads, num_seqs), one wave. Follows attention_kernels.cu:567-669.
+template <typename scalar_t>
+__global__ void paged_attention_v2_reduce_kernel(scalar_t* __restrict__ out, const float* __restrict__ exp_sums,
+                                                 const float* __restrict__ max_logits,
+                                                 const scalar_t* __restrict__ tmp_out,
+                                                 const int32_t* __restrict__ seq_lens, int max_num_partitions,
+                                                 int head_size) {
+  const int head = blockIdx.x, num_heads = gridDim.x, seq = blockIdx.y;
+  const int seq_len = seq_lens[seq];
+  const int np = (seq_len + kPartitionSize - 1) / kPartitionSize;
+  const int64_t pb = ((int64_t)seq * num_heads + head) * max_num_partitions;
+  scalar_t* o = out + ((int64_t)seq * num_heads + head) * head_size;
+  const scalar_t* tp = tmp_out + pb * head_size;
+  if (np <= 1) {
+    for (int i = threadIdx.x; i < head_size; i += blockDim.x) o[i] = tp[i];
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* resc = reinterpret_cast<float*>(smem);  // [np]
+  float m = -FLT_MAX;
+  for (int i = threadIdx.x; i < np; i += 64) m = fmaxf(m, max_logits[pb + i]);
+  m = wave_reduce_max(m);
+  float gsum = 0.f;
+  for (int i = threadIdx.x; i < np; i += 64) {
+    const float r = exp_sums[pb + i] * __expf(max_logits[pb + i] - m);
+    resc[i] = r;
+    gsum += r;
+  }
+  gsum = wave_reduce_sum(gsum);
+  __syncthreads();
+  const float inv = __fdividef(1.f, gsum + 1e-6f);
+  for (int d = threadIdx.x; d < head_size; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < np; ++j) acc += Scalar<scalar_t>::to_f32(tp[(int64_t)j * head_size + d]) * resc[j] * inv;
+    o[d] = Scalar<scalar_t>::from_f32(acc);
+  }
+}
+
+template <typename scalar_t, int KV, int D>
+int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream_t stream) {
+  constexpr int NW = 4;
+  const size_t smem = (size_t)NW * 16 * (2 + D) * sizeof(float);
+  dim3 grid(p.num_kv_heads * p.q_tiles, num_seqs, num_partitions);
+  auto kern = paged_attention_kernel<scalar_t, KV, D, NW>;
+  if (smem > 64 * 1024) {
+    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  }
+  kern<<<grid, dim3(NW * 64), smem, stream>>>(p);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+template <typename scalar_t, int KV>
+int dispatch_head(const AttnParams& p, int head_size, int num_seqs, int num_partitions, hipStream_t stream) {
+  switch (head_size) {
+    case 64: return launch_attn<scalar_t, KV, 64>(p, num_seqs, num_partitions, stream);
+    case 80: return launch_attn<scalar_t, KV, 80>(p, num_seqs, num_partitions, stream);
+    case 96: return launch_attn<scalar_t, KV, 96>(p, num_seqs, num_partitions, stream);
+    case 112: return launch_attn<scalar_t, KV, 112>(p, num_seqs, num_partitions, stream);
+    case 128: return launch_attn<scalar_t, KV, 128>(p, num_seqs, num_partitions, stream);
+    case 192: return launch_attn<scalar_t, KV, 192>(p, num_seqs, num_partitions, stream);
+    case 256: return launch_attn<scalar_t, KV, 256>(p, num_seqs, num_partitions, stream);
+    default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "Unsupported head size: %d", head_size);
+  }
+}
+
+template <typename scalar_t>
+int dispatch_kv(const AttnParams& p, int kv_dtype, int head_size, int num_seqs, int num_partitions, hipStream_t stream) {
+  switch (kv_dtype) {
+    case NMX_KV_AUTO: return dispatch_head<scalar_t, NMX_KV_AUTO>(p, head_size, num_seqs, num_partitions, stream);
+    case NMX_KV_FP8_E4M3: return dispatch_head<scalar_t, NMX_KV_FP8_E4M3>(p, head_size, num_seqs, num_partitions, stream);
+    case NMX_KV_FP8_E5M2: return dispatch_head<scalar_t, NMX_KV_FP8_E5M2>(p, head_size, num_seqs, num_partitions, stream);
+    default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "Unsupported data type of kv cache: %d", kv_dtype);
+  }
+}
+
+int run_attention(bool partitioned, void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+                  const void* key_cache, const void* value_cache, int num_seqs, int num_heads, int num_kv_heads,
+                  int head_size, int block_size, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                  float scale, const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                  int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
+                  int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
+                  hipStream_t stream) {
+  NMX_CHECK(block_size == 8 || block_size == 16 || block_size == 32, NMX_ERR_UNSUPPORTED,
+            "Unsupported block size: %d", block_size);
+  NMX_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, NMX_ERR_INVALID_ARG,
+            "num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
+  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED,
+            "paged_attention: unsupported query dtype code %d (float16 / bfloat16 only on gfx950)", dtype);
+  NMX_CHECK(((uintptr_t)query % 16 == 0) && (q_stride % 8 == 0), NMX_ERR_INVALID_ARG,
+            "paged_attention: query must be 16-byte aligned with a row stride that is a multiple of 8 elements");
+  NMX_CHECK(((uintptr_t)key_cache % 16 == 0) && ((uintptr_t)value_cache % 16 == 0) && kv_block_stride % 16 == 0 &&
+                kv_head_stride % 16 == 0,
+            NMX_ERR_INVALID_ARG, "paged_attention: KV cache must be 16-byte aligned");
+  if (num_seqs == 0) return NMX_OK;
+
+  AttnParams p;
+  p.out = partitioned ? tmp_out : out;
+  p.exp_sums = exp_sums;
+  p.max_logits = max_logits;
+  p.q = query;
+  p.k_cache = key_cache;
+  p.v_cache = value_cache;
+  p.block_tables = block_tables;
+  p.seq_lens = seq_lens;
+  p.alibi_slopes = alibi_slopes;
+  p.q_stride = q_stride;
+  p.kv_block_stride = kv_block_stride;
+  p.kv_head_stride = kv_head_stride;
+  p.scale = scale;
+  p.kv_scale = kv_scale;
+  p.num_heads = num_heads;
+  p.num_kv_heads = num_kv_heads;
+  p.q_per_kv = num_heads / num_kv_heads;
+  p.q_tiles = (p.q_per_kv + 15) / 16;
+  p.max_blocks_per_seq = max_num_blocks_per_seq;
+  p.block_size = block_size;
+  p.bs_shift = block_size == 8 ? 3 : (block_size == 16 ? 4 : 5);
+  p.partitioned = partitioned ? 1 : 0;
+  const int num_partitions = partitioned ? (max_seq_len + kPartitionSize - 1) / kPartitionSize : 1;
+  p.max_num_partitions = num_partitions;
+  p.sparse = bs_vert_stride > 1 ? 1 : 0;  // attention_kernels.cu:822
+  p.tp_rank = tp_rank;
+  p.bs_local_blocks = bs_local_blocks;
+  p.bs_vert_stride = bs_vert_stride;
+  p.bs_block_size = bs_block_size;
+  p.bs_head_sliding_step = bs_head_sliding_step;
+  if (p.sparse) NMX_CHECK(bs_block_size > 0, NMX_ERR_INVALID_ARG, "blocksparse_block_size must be > 0");
+  if (partitioned && num_partitions == 0) return NMX_OK;
+
+  int rc;
+  if (dtype == NMX_F16) rc = dispatch_kv<f16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
+  else rc = dispatch_kv<bf16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
+  if (rc != NMX_OK || !partitioned) return rc;
+
+  dim3 rgrid(num_heads, num_seqs);
+  const size_t rsmem = (size_t)num_partitions * sizeof(float);
+  if (dtype == NMX_F16)
+    paged_attention_v2_reduce_kernel<f16><<<rgrid, 64, rsmem, stream>>>((f16*)out, exp_sums, max_logits, (const f16*)tmp_out,
+                                                                        seq_lens, num_partitions, head_size);
+  else
+    paged_attention_v2_reduce_kernel<bf16><<<rgrid, 64, rsmem, stream>>>((bf16*)out, exp_sums, max_logits,
+                                                                         (const bf16*)tmp_out, seq_lens, num_partitions,
+                                                                         head_size);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+}  // namespace
+
+extern "C" int nmx_paged_attention_v1(void* out, const void* query, const void* key_cache, const void* value_cache,
+                                      int num_seqs, int num_heads, int num_kv_heads, int head_size, int block_size,
+                                      int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                                      const int32_t* block_tables, int max_num_blocks_per_seq,
+                                      const int32_t* seq_lens, int max_seq_len, const float* alibi_slopes, int dtype,
+                                      int kv_dtype, float kv_scale, int tp_rank, int bs_local_blocks,
+                                      int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
+                                      nmx_stream_t stream) {
+  return run_attention(false, out, nullptr, nullptr, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
+                       num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
+                       block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
+                       kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
+                       (hipStream_t)stream);
+}
+
+extern "C" int nmx_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                                      const void* query, const void* key_cache, const void* value_cache,
+                                      int num_seqs, int num_heads, int num_kv_heads, int head_size, int block_size,
+                                      int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                                      const int32_t* block_tables, int max_num_blocks_per_seq,
+                                      const int32_t* seq_lens, int max_seq_len, const float* alibi_slopes, int dtype,
+                                      int kv_dtype, float kv_scale, int tp_rank, int bs_local_blocks,
+                                      int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
+                                      nmx_stream_t stream) {
+  return run_attention(true, out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+                       num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
+                       block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
+                       kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
+                       (hipStream_t)stream);
+}
