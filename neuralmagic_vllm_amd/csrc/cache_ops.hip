@@ -123,8 +123,11 @@ __global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restric
       const float v = Scalar<scalar_t>::to_f32(reinterpret_cast<const scalar_t*>(src)[i]);
       reinterpret_cast<uint8_t*>(dst)[i] = f32_to_fp8_sat<KV>(v / scale);
     } else {
-      const float v = fp8_to_f32<KV>(reinterpret_cast<const uint8_t*>(src)[i]);
-      reinterpret_cast<scalar_t*>(dst)[i] = Scalar<scalar_t>::from_f32(v * scale);
+      float v = fp8_to_f32<KV>(reinterpret_cast<const uint8_t*>(src)[i]) * scale;
+      // keep the multiply and the narrowing conversion separate: hipcc otherwise fuses them into
+      // v_fma_mixlo_f16(scale, v, +0), which turns -0 into +0 (the reference keeps the sign of zero)
+      asm volatile("" : "+v"(v));
+      reinterpret_cast<scalar_t*>(dst)[i] = Scalar<scalar_t>::from_f32(v);
     }
   }
 }

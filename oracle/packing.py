@@ -53,7 +53,7 @@ def gptq_pack(q_w: torch.Tensor, num_bits: int, size_k: int, size_n: int) -> tor
     q = q_w.cpu().numpy().astype(np.uint32).reshape(size_k // pf, pf, size_n)
     shifts = (np.arange(pf, dtype=np.uint32) * num_bits)[None, :, None]
     packed = np.bitwise_or.reduce(q << shifts, axis=1)
-    return torch.from_numpy(packed.astype(np.int32))
+    return torch.from_numpy(np.ascontiguousarray(packed.astype(np.int32)))
 
 
 def gptq_pack_zeros(z: torch.Tensor, num_bits: int) -> torch.Tensor:
@@ -62,7 +62,7 @@ def gptq_pack_zeros(z: torch.Tensor, num_bits: int) -> torch.Tensor:
     G, N = z.shape
     zz = ((z.cpu().numpy().astype(np.int64) - 1) & (2**num_bits - 1)).astype(np.uint32).reshape(G, N // pf, pf)
     shifts = (np.arange(pf, dtype=np.uint32) * num_bits)[None, None, :]
-    return torch.from_numpy(np.bitwise_or.reduce(zz << shifts, axis=2).astype(np.int32))
+    return torch.from_numpy(np.ascontiguousarray(np.bitwise_or.reduce(zz << shifts, axis=2).astype(np.int32)))
 
 
 # ---- Marlin layout: marlin_perms.py:16-50, marlin_utils.py:25-57 (element map: SURVEY.md appendix A.2) ----
@@ -84,7 +84,7 @@ def marlin_weights(q_w: torch.Tensor, size_k: int, size_n: int, num_bits: int) -
     q = q.reshape(-1, 1024)[:, perm].reshape(size_k // 16, size_n * 16)
     q = q.reshape(size_k // 16, size_n * 16 // pf, pf)
     shifts = (np.arange(pf, dtype=np.uint32) * num_bits)[None, None, :]
-    return torch.from_numpy(np.bitwise_or.reduce(q << shifts, axis=2).astype(np.int32))
+    return torch.from_numpy(np.ascontiguousarray(np.bitwise_or.reduce(q << shifts, axis=2).astype(np.int32)))
 
 
 _SCALE_PERM = [i + 8 * j for i in range(8) for j in range(8)]
@@ -133,7 +133,7 @@ def awq_pack(q: torch.Tensor) -> torch.Tensor:
     R, N = q.shape
     v = q.cpu().numpy().astype(np.uint32).reshape(R, N // 8, 8)
     shifts = (4 * _AWQ_ORDER).astype(np.uint32)[None, None, :]
-    return torch.from_numpy(np.bitwise_or.reduce(v << shifts, axis=2).astype(np.int32))
+    return torch.from_numpy(np.ascontiguousarray(np.bitwise_or.reduce(v << shifts, axis=2).astype(np.int32)))
 
 
 def awq_quantize(w: torch.Tensor, group_size: int, generator: Optional[torch.Generator] = None):

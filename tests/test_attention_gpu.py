@@ -1,0 +1,220 @@
+"""GPU parity tests for paged_attention_v1 / v2 (HIP, through the C-ABI) against the CPU oracle, the fp32 torch
+restatement of the reference test's expected value, and the reference-made golden vectors.
+Mirrors tests/kernels/test_attention.py:119-284 of the reference (tolerance atol 1e-3 / rtol 1e-5; fp8 KV atol 1e-2)."""
+import random
+
+import pytest
+import torch
+
+import oracle
+from util import (DTYPES, create_kv_caches_with_random, from_bits, load_golden, ref_single_query_cached_kv_attention,
+                  seed_all)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PARTITION = 512
+
+
+def run_hip(ops, version, q, kc, vc, kvh, scale, bt, sl, block_size, max_len, alibi, kv_dtype, kv_scale, **bs):
+    qg = q.to(DEV)
+    out = torch.full_like(qg, float("nan"))
+    al = alibi.to(DEV) if alibi is not None else None
+    if version == "v1":
+        ops.paged_attention_v1(out, qg, kc.to(DEV), vc.to(DEV), kvh, scale, bt.to(DEV), sl.to(DEV), block_size, max_len,
+                               al, kv_dtype, kv_scale, **bs)
+    else:
+        S, H, D = q.shape
+        P = (max_len + PARTITION - 1) // PARTITION
+        tmp = torch.empty(S, H, P, D, dtype=q.dtype, device=DEV)
+        es = torch.empty(S, H, P, dtype=torch.float32, device=DEV)
+        ml = torch.empty(S, H, P, dtype=torch.float32, device=DEV)
+        ops.paged_attention_v2(out, es, ml, tmp, qg, kc.to(DEV), vc.to(DEV), kvh, scale, bt.to(DEV), sl.to(DEV),
+                               block_size, max_len, al, kv_dtype, kv_scale, **bs)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def run_oracle(version, q, kc, vc, kvh, scale, bt, sl, block_size, max_len, alibi, kv_dtype, kv_scale, **bs):
+    out = torch.empty_like(q)
+    if version == "v1":
+        oracle.paged_attention_v1(out, q, kc, vc, kvh, scale, bt, sl, block_size, max_len, alibi, kv_dtype, kv_scale, **bs)
+    else:
+        S, H, D = q.shape
+        P = (max_len + PARTITION - 1) // PARTITION
+        tmp = torch.empty(S, H, P, D, dtype=q.dtype)
+        es = torch.empty(S, H, P, dtype=torch.float32)
+        ml = torch.empty(S, H, P, dtype=torch.float32)
+        oracle.paged_attention_v2(out, es, ml, tmp, q, kc, vc, kvh, scale, bt, sl, block_size, max_len, alibi, kv_dtype,
+                                  kv_scale, **bs)
+    return out
+
+
+@pytest.mark.parametrize("name", ["attn_bf16_gqa", "attn_bf16_alibi_mha"])
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_attention_golden(ops, name, version):
+    """Outputs of the reference's own CPU backend (bf16; the reference CPU backend has no fp16)."""
+    g = load_golden(name)
+    dt = DTYPES[str(g["dtype"])]
+    q, kc, vc = from_bits(g["q"], dt), from_bits(g["k_cache"], dt), from_bits(g["v_cache"], dt)
+    bt, sl = torch.from_numpy(g["block_tables"]), torch.from_numpy(g["seq_lens"])
+    al = torch.from_numpy(g["alibi_slopes"]) if "alibi_slopes" in g.files else None
+    out = run_hip(ops, version, q, kc, vc, int(g["num_kv_heads"]), float(g["scale"]), bt, sl, 16,
+                  int(g["max_seq_len"]), al, "auto", 1.0)
+    # bf16 outputs: one bf16 ulp at |x| <= 0.125 is 4.9e-4
+    torch.testing.assert_close(out.float(), from_bits(g["out_" + version], dt).float(), atol=2e-3, rtol=1e-5)
+
+
+NUM_BLOCKS = 1031
+MAX_SEQ_LEN = 2100
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("num_heads", [(40, 40), (64, 8), (8, 1)])
+@pytest.mark.parametrize("head_size", [64, 80, 96, 112, 128, 192, 256])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("use_alibi", [False, True])
+def test_paged_attention(ops, version, num_heads, head_size, block_size, dtype, use_alibi):
+    if use_alibi and (head_size not in (64, 128) or block_size != 16):
+        pytest.skip("alibi covered on a subset")
+    seed_all(0)
+    num_seqs = 7
+    nq, nkv = num_heads
+    scale = float(head_size**-0.5)
+    q = torch.empty(num_seqs, nq, head_size, dtype=dtype).uniform_(-scale, scale)
+    seq_lens = [random.randint(1, MAX_SEQ_LEN) for _ in range(num_seqs)]
+    seq_lens[-1] = MAX_SEQ_LEN
+    seq_lens[0] = 1
+    seq_lens[1] = 513
+    max_len = max(seq_lens)
+    mb = (max_len + block_size - 1) // block_size
+    bt = torch.tensor([[random.randint(0, NUM_BLOCKS - 1) for _ in range(mb)] for _ in range(num_seqs)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(NUM_BLOCKS, block_size, 1, nkv, head_size, "auto", dtype)
+    kc, vc = kcs[0], vcs[0]
+    alibi = torch.randn(nq, dtype=torch.float32) if use_alibi else None
+    out = run_hip(ops, version, q, kc, vc, nkv, scale, bt, sl, block_size, max_len, alibi, "auto", 1.0)
+    ref = ref_single_query_cached_kv_attention(q, nq // nkv, kc, vc, bt, sl, scale, alibi)
+    torch.testing.assert_close(out.float(), ref, atol=1e-3, rtol=1e-5)
+    if head_size == 128 and block_size == 16:
+        orc = run_oracle(version, q, kc, vc, nkv, scale, bt, sl, block_size, max_len, alibi, "auto", 1.0)
+        torch.testing.assert_close(out.float(), orc.float(), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("block_size", [8, 16, 32])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("kv_dtype", ["fp8", "fp8_e5m2"])
+def test_paged_attention_fp8_kv(ops, version, block_size, dtype, kv_dtype):
+    seed_all(1)
+    num_seqs, nq, nkv, head_size = 5, 32, 8, 128
+    scale = float(head_size**-0.5)
+    kv_scale = 0.75
+    q = torch.empty(num_seqs, nq, head_size, dtype=dtype).uniform_(-scale, scale)
+    seq_lens = [700, 1, 33, 512, 1025]
+    max_len = max(seq_lens)
+    mb = (max_len + block_size - 1) // block_size
+    bt = torch.tensor([[random.randint(0, 255) for _ in range(mb)] for _ in range(num_seqs)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(256, block_size, 1, nkv, head_size, kv_dtype, dtype)
+    out = run_hip(ops, version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
+    orc = run_oracle(version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
+    torch.testing.assert_close(out.float(), orc.float(), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("sliding_step", [0, 1, -1])
+def test_paged_attention_blocksparse(ops, version, sliding_step):
+    """Block-sparse path (attention_kernels.cu:209-256; Phi-3-small style: local 16 blocks, vertical stride 8)."""
+    seed_all(2)
+    num_seqs, nq, nkv, head_size, block_size = 4, 16, 4, 128, 16
+    scale = float(head_size**-0.5)
+    q = torch.empty(num_seqs, nq, head_size, dtype=torch.half).uniform_(-scale, scale)
+    seq_lens = [1500, 64, 777, 2048]
+    max_len = max(seq_lens)
+    mb = (max_len + block_size - 1) // block_size
+    bt = torch.tensor([[random.randint(0, 511) for _ in range(mb)] for _ in range(num_seqs)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(512, block_size, 1, nkv, head_size, "auto", torch.half)
+    bs = dict(tp_rank=1, blocksparse_local_blocks=4, blocksparse_vert_stride=8, blocksparse_block_size=64,
+              blocksparse_head_sliding_step=sliding_step)
+    out = run_hip(ops, version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, "auto", 1.0, **bs)
+    orc = run_oracle(version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, "auto", 1.0, **bs)
+    torch.testing.assert_close(out.float(), orc.float(), atol=1e-3, rtol=1e-5)
+
+
+def test_paged_attention_strided_query_and_nan_tail(ops):
+    """query sliced out of a fused qkv tensor (q_stride != H*D) and NaNs parked past seq_len in the last block."""
+    seed_all(3)
+    num_seqs, nq, nkv, head_size, block_size = 3, 32, 8, 128, 16
+    scale = float(head_size**-0.5)
+    qkv = torch.empty(num_seqs, (nq + 2 * nkv) * head_size, dtype=torch.half).uniform_(-scale, scale)
+    q = qkv[:, :nq * head_size].view(num_seqs, nq, head_size)
+    seq_lens = [37, 300, 5]
+    bt = torch.arange(num_seqs * 19, dtype=torch.int32).reshape(num_seqs, 19)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(64, block_size, 1, nkv, head_size, "auto", torch.half)
+    kc, vc = kcs[0], vcs[0]
+    for i, L in enumerate(seq_lens):  # poison everything past the end of each sequence's last block
+        b = int(bt[i, (L - 1) // block_size])
+        o = L % block_size
+        if o:
+            kc[b, :, :, o:, :] = float("nan")
+            vc[b, :, :, o:] = float("nan")
+    qg = qkv.to(DEV)[:, :nq * head_size].view(num_seqs, nq, head_size)
+    out = torch.empty(num_seqs, nq, head_size, dtype=torch.half, device=DEV)
+    ops.paged_attention_v1(out, qg, kc.to(DEV), vc.to(DEV), nkv, scale, bt.to(DEV), sl.to(DEV), block_size, 300, None, "auto", 1.0)
+    ref = ref_single_query_cached_kv_attention(q, nq // nkv, kc, vc, bt, sl, scale, None)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.cpu().float(), ref, atol=1e-3, rtol=1e-5)
+
+
+def test_paged_attention_rejects_bad_arguments(ops):
+    q = torch.zeros(2, 8, 72, dtype=torch.half, device=DEV)
+    kc = torch.zeros(4, 8, 9, 16, 8, dtype=torch.half, device=DEV)
+    vc = torch.zeros(4, 8, 72, 16, dtype=torch.half, device=DEV)
+    bt = torch.zeros(2, 4, dtype=torch.int32, device=DEV)
+    sl = torch.ones(2, dtype=torch.int32, device=DEV)
+    out = torch.zeros_like(q)
+    with pytest.raises(RuntimeError, match="Unsupported head size"):
+        ops.paged_attention_v1(out, q, kc, vc, 8, 1.0, bt, sl, 16, 16, None, "auto", 1.0)
+    q = torch.zeros(2, 8, 64, dtype=torch.half, device=DEV)
+    out = torch.zeros_like(q)
+    with pytest.raises(RuntimeError, match="Unsupported block size"):
+        ops.paged_attention_v1(out, q, kc, vc, 8, 1.0, bt, sl, 4, 16, None, "auto", 1.0)
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
+        ops.paged_attention_v1(out, q, kc, vc, 8, 1.0, bt, sl, 16, 16, None, "int3", 1.0)
+
+
+def test_large_batch_property(ops):
+    """BASELINE-size case (64 seqs x 1024 ctx, Llama-3-8B geometry): size-independent properties instead of the slow
+    oracle — (i) v1 == v2, (ii) permuting the physical blocks (with the block table) leaves the output unchanged."""
+    seed_all(4)
+    S, nq, nkv, D, BS, L = 64, 32, 8, 128, 16, 1024
+    scale = float(D**-0.5)
+    NB = S * L // BS
+    q = torch.empty(S, nq, D, dtype=torch.half, device=DEV).uniform_(-scale, scale)
+    kc = torch.empty(NB, nkv, D // 8, BS, 8, dtype=torch.half, device=DEV).uniform_(-scale, scale)
+    vc = torch.empty(NB, nkv, D, BS, dtype=torch.half, device=DEV).uniform_(-scale, scale)
+    bt = torch.randperm(NB, device=DEV).to(torch.int32).reshape(S, L // BS)
+    sl = torch.full((S, ), L, dtype=torch.int32, device=DEV)
+    out1 = torch.empty_like(q)
+    ops.paged_attention_v1(out1, q, kc, vc, nkv, scale, bt, sl, BS, L, None, "auto", 1.0)
+    out2 = torch.empty_like(q)
+    P = L // PARTITION
+    tmp = torch.empty(S, nq, P, D, dtype=torch.half, device=DEV)
+    es = torch.empty(S, nq, P, dtype=torch.float32, device=DEV)
+    ml = torch.empty(S, nq, P, dtype=torch.float32, device=DEV)
+    ops.paged_attention_v2(out2, es, ml, tmp, q, kc, vc, nkv, scale, bt, sl, BS, L, None, "auto", 1.0)
+    torch.testing.assert_close(out1.float(), out2.float(), atol=1e-3, rtol=1e-5)
+    perm = torch.randperm(NB, device=DEV)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(NB, device=DEV)
+    out3 = torch.empty_like(q)
+    ops.paged_attention_v1(out3, q, kc[perm].contiguous(), vc[perm].contiguous(), nkv, scale,
+                           inv[bt.long()].to(torch.int32), sl, BS, L, None, "auto", 1.0)
+    assert torch.equal(out1, out3)
+    # spot-check 2 sequences against the oracle
+    idx = [0, 37]
+    o = run_oracle("v1", q[idx].cpu(), kc.cpu(), vc.cpu(), nkv, scale, bt[idx].cpu(), sl[idx].cpu(), BS, L, None, "auto", 1.0)
+    torch.testing.assert_close(out1[idx].cpu().float(), o.float(), atol=1e-3, rtol=1e-5)
