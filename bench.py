@@ -1,0 +1,391 @@
+#!/usr/bin/env python3
+"""bench.py — decode-step throughput of the hot path on MI355X, Llama-3-8B GPTQ-int4 (Marlin format) TP=1.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
+  step      = one decode step of the whole batch through 32 decoder layers + lm_head:
+              per layer RMSNorm -> int4 qkv GEMM -> RoPE -> reshape_and_cache -> paged_attention -> int4 o_proj GEMM
+              -> RMSNorm(+residual) -> int4 gate_up GEMM -> SiLU*mul -> int4 down GEMM; then final norm, fp16 lm_head,
+              greedy argmax. The four int4 GEMMs, the KV write and the attention are this repo's HIP kernels called
+              through the C-ABI; the element-wise neighbours (RMSNorm / RoPE / SiLU, SURVEY §8f "next") and the fp16
+              lm_head run as plain torch ops. The step is captured in a HIP graph (the reference decodes under CUDA
+              graphs too: vllm/worker/model_runner.py:910-1111).
+  value     = decoded tokens / s over all ranks (each rank = an independent TP=1 replica: weak scaling).
+  roofline  = the kernel class with the largest share of the step, timed with HIP events on the launch stream.
+  cpu_baseline = the CPU oracle (a port: dequant + fp32 matmul, scalar attention) on a bounded sample, rank 0 only.
+Synthetic data: random token ids / activations, random-init int4 weights of the Llama-3-8B shapes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16
+
+LLAMA3_8B = dict(hidden=4096, inter=14336, heads=32, kv_heads=8, head=128, layers=32, vocab=128256, group=128)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="sequences decoded per step and per GPU")
+    ap.add_argument("--ctx", type=int, default=1024, help="KV context length of every sequence")
+    ap.add_argument("--layers", type=int, default=LLAMA3_8B["layers"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
+    return ap.parse_args()
+
+
+def random_marlin_weight(K, N, group, device, gen):
+    """Random-init int4 weight already in Marlin layout: any int32 word is a valid packed tile row
+    ([K/16, N*16/8]); scales [K/group, N] fp16 (Marlin-permuted order is irrelevant for random values)."""
+    q = torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32, device=device, generator=gen)
+    s = (torch.rand(K // group, N, device=device, generator=gen) * 0.004 + 0.002).to(torch.float16)
+    return q, s
+
+
+class Llama3Decode:
+    """Synthetic Llama-3-8B decode step driver (the *caller* of the hot path; stands in for vllm's LlamaForCausalLM)."""
+
+    def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16):
+        self.ops, self.cfg, self.B, self.L, self.dev = ops, cfg, batch, ctx, device
+        self.n_layers = n_layers
+        H, I, nh, nkv, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head"]
+        self.q_size, self.kv_size = nh * D, nkv * D
+        g = torch.Generator(device=device)
+        g.manual_seed(0)
+        self.shapes = dict(qkv=(H, self.q_size + 2 * self.kv_size), o=(self.q_size, H), gate_up=(H, 2 * I), down=(I, H))
+        self.layers = []
+        for _ in range(n_layers):
+            lw = {}
+            for name, (K, N) in self.shapes.items():
+                lw[name] = random_marlin_weight(K, N, cfg["group"], device, g)
+            lw["ln1"] = torch.ones(H, dtype=torch.float16, device=device)
+            lw["ln2"] = torch.ones(H, dtype=torch.float16, device=device)
+            self.layers.append(lw)
+        self.final_ln = torch.ones(H, dtype=torch.float16, device=device)
+        self.lm_head = (torch.randn(cfg["vocab"], H, generator=g, device=device, dtype=torch.float16) * 0.02)
+        self.embed = (torch.randn(cfg["vocab"], H, generator=g, device=device, dtype=torch.float16) * 0.02)
+        # paged KV cache: every sequence owns ctx tokens; blocks scattered by a random permutation
+        self.BS = block_size
+        blocks_per_seq = (ctx + block_size - 1) // block_size
+        NB = batch * blocks_per_seq
+        scale = D**-0.5
+        self.kv = []
+        for _ in range(n_layers):
+            kc = torch.empty(NB, nkv, D // 8, block_size, 8, dtype=torch.float16, device=device).uniform_(-scale, scale, generator=g)
+            vc = torch.empty(NB, nkv, D, block_size, dtype=torch.float16, device=device).uniform_(-scale, scale, generator=g)
+            self.kv.append((kc, vc))
+        self.block_tables = torch.randperm(NB, generator=g, device=device).to(torch.int32).reshape(batch, blocks_per_seq)
+        self.seq_lens = torch.full((batch, ), ctx, dtype=torch.int32, device=device)
+        last = ctx - 1  # the new token is written at position ctx-1 and attended with the ctx-1 cached ones
+        self.slot_mapping = (self.block_tables[:, last // block_size].long() * block_size + last % block_size)
+        self.positions = torch.full((batch, ), last, dtype=torch.long, device=device)
+        inv_freq = 1.0 / (500000.0**(torch.arange(0, D, 2, device=device).float() / D))
+        ang = self.positions.float()[:, None] * inv_freq[None, :]
+        self.cos, self.sin = ang.cos()[:, None, :].half(), ang.sin()[:, None, :].half()
+        self.tokens = torch.randint(0, cfg["vocab"], (batch, ), generator=g, device=device)
+        self.workspace = torch.zeros(max(N for _, N in self.shapes.values()) // 64 * 16, dtype=torch.int32, device=device)
+        self.empty = torch.empty(0, dtype=torch.int32, device=device)
+        self.scale = float(scale)
+        # v2 temporaries (vllm/attention/ops/paged_attn.py:148-158)
+        self.P = (ctx + 511) // 512
+        self.use_v1 = ctx <= 8192 and (self.P == 1 or batch * nh > 512)  # paged_attn.py:120-121
+        if not self.use_v1:
+            self.tmp_out = torch.empty(batch, nh, self.P, D, dtype=torch.float16, device=device)
+            self.exp_sums = torch.empty(batch, nh, self.P, dtype=torch.float32, device=device)
+            self.max_logits = torch.empty(batch, nh, self.P, dtype=torch.float32, device=device)
+        self.next_tokens = torch.zeros(batch, dtype=torch.long, device=device)
+
+    # -- caller-side element-wise neighbours (plain torch; out of the hot-path scope for now) --
+    @staticmethod
+    def rms_norm(x, w, eps=1e-5):
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype) * w
+
+    def rope(self, x):  # x [B, heads, D], NeoX style
+        x1, x2 = x[..., :x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+        return torch.cat((x1 * self.cos - x2 * self.sin, x2 * self.cos + x1 * self.sin), dim=-1)
+
+    def gemm(self, x, w, name):
+        K, N = self.shapes[name]
+        return self.ops.gptq_marlin_gemm(x, w[0], w[1], self.empty, self.empty, self.workspace, 4, x.shape[0], N, K, True)
+
+    def attention(self, q, layer):
+        cfg = self.cfg
+        kc, vc = self.kv[layer]
+        out = torch.empty_like(q)
+        if self.use_v1:
+            self.ops.paged_attention_v1(out, q, kc, vc, cfg["kv_heads"], self.scale, self.block_tables, self.seq_lens,
+                                        self.BS, self.L, None, "auto", 1.0)
+        else:
+            self.ops.paged_attention_v2(out, self.exp_sums, self.max_logits, self.tmp_out, q, kc, vc, cfg["kv_heads"],
+                                        self.scale, self.block_tables, self.seq_lens, self.BS, self.L, None, "auto", 1.0)
+        return out
+
+    def step(self):
+        cfg = self.cfg
+        nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
+        h = self.embed[self.tokens]
+        resid = None
+        for li, lw in enumerate(self.layers):
+            if resid is None:
+                resid = h
+            else:
+                resid = resid + h
+            x = self.rms_norm(resid, lw["ln1"])
+            qkv = self.gemm(x, lw["qkv"], "qkv")
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            q = self.rope(q.reshape(-1, nh, D))
+            k = self.rope(k.reshape(-1, nkv, D))
+            v = v.reshape(-1, nkv, D)
+            kc, vc = self.kv[li]
+            self.ops.reshape_and_cache(k, v, kc, vc, self.slot_mapping, "auto", 1.0)
+            a = self.attention(q.contiguous(), li)
+            h = self.gemm(a.reshape(-1, nh * D), lw["o"], "o")
+            resid = resid + h
+            x = self.rms_norm(resid, lw["ln2"])
+            gu = self.gemm(x, lw["gate_up"], "gate_up")
+            act = torch.nn.functional.silu(gu[:, :cfg["inter"]]) * gu[:, cfg["inter"]:]
+            h = self.gemm(act, lw["down"], "down")
+        x = self.rms_norm(resid + h, self.final_ln)
+        logits = torch.matmul(x, self.lm_head.t())
+        self.next_tokens.copy_(logits.argmax(-1))
+        return self.next_tokens
+
+
+def gemm_bytes(M, K, N, group):
+    return K * N // 2 + (K // group) * N * 2 + 2 * M * K + 2 * M * N
+
+
+def time_events(fn, reps):
+    """Average device time of fn() in ms: fn's launches are captured into a HIP graph (so that Python / ctypes launch
+    overhead does not pollute kernels that last a few microseconds) and the graph replays are bracketed by HIP
+    events on the launch stream."""
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps  # ms
+
+
+def kernel_breakdown(model, reps=3):
+    """Per kernel class: avg launch duration (HIP events on the launch stream, all layers' distinct buffers in turn),
+    algorithmic bytes / flops per launch, achieved GB/s."""
+    B, cfg = model.B, model.cfg
+    out = {}
+    nl = model.n_layers
+    for name, (K, N) in model.shapes.items():
+        x = torch.randn(B, K, dtype=torch.float16, device=model.dev)
+
+        def run(name=name, x=x):
+            for lw in model.layers:
+                model.gemm(x, lw[name], name)
+
+        run()
+        ms = time_events(run, reps) / nl
+        by = gemm_bytes(B, K, N, cfg["group"])
+        fl = 2.0 * B * K * N
+        out["int4_gemm_" + name] = dict(ms=ms, bytes=by, flops=fl, gbs=by / ms / 1e6, tflops=fl / ms / 1e9, launches=nl)
+    q = torch.randn(B, cfg["heads"], cfg["head"], dtype=torch.float16, device=model.dev) * 0.1
+
+    def run_attn():
+        for li in range(nl):
+            model.attention(q, li)
+
+    run_attn()
+    ms = time_events(run_attn, reps) / nl
+    by = 2 * B * model.L * cfg["kv_heads"] * cfg["head"] * 2 + 2 * B * cfg["heads"] * cfg["head"] * 2
+    fl = 4.0 * B * model.L * cfg["heads"] * cfg["head"]
+    out["paged_attention_" + ("v1" if model.use_v1 else "v2")] = dict(ms=ms, bytes=by, flops=fl, gbs=by / ms / 1e6,
+                                                                      tflops=fl / ms / 1e9, launches=nl)
+    return out
+
+
+def cpu_baseline(cfg, batch, ctx):
+    """Times the CPU oracle (port) on ONE decoder layer's hot-path ops at this batch; scaled to 32 layers."""
+    import oracle
+    from oracle import packing
+    torch.manual_seed(0)
+    H, I, nh, nkv, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head"]
+    shapes = [(H, (nh + 2 * nkv) * D), (nh * D, H), (H, 2 * I), (I, H)]
+    t_total = 0.0
+    cpu_batch = min(batch, 8)  # bounded sample: 8 rows of the batch
+    for K, N in shapes:
+        mq = torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32)
+        ms = (torch.rand(K // cfg["group"], N) * 0.01 + 0.005).half()
+        a = torch.randn(cpu_batch, K, dtype=torch.float16)
+        t0 = time.perf_counter()
+        oracle.gptq_marlin_gemm(a, mq, ms, None, None, None, 4, cpu_batch, N, K, True)
+        t_total += time.perf_counter() - t0
+    # attention on cpu_batch sequences
+    BS = 16
+    nb = cpu_batch * ((ctx + BS - 1) // BS)
+    kc = torch.empty(nb, nkv, D // 8, BS, 8, dtype=torch.float16).uniform_(-0.1, 0.1)
+    vc = torch.empty(nb, nkv, D, BS, dtype=torch.float16).uniform_(-0.1, 0.1)
+    q = torch.empty(cpu_batch, nh, D, dtype=torch.float16).uniform_(-0.1, 0.1)
+    bt = torch.randperm(nb).to(torch.int32).reshape(cpu_batch, -1)
+    sl = torch.full((cpu_batch, ), ctx, dtype=torch.int32)
+    out = torch.empty_like(q)
+    t0 = time.perf_counter()
+    oracle.paged_attention_v1(out, q, kc, vc, nkv, D**-0.5, bt, sl, BS, ctx, None, "auto", 1.0)
+    t_total += time.perf_counter() - t0
+    step_s = t_total * cfg["layers"]
+    return dict(value=cpu_batch / step_s, unit="tokens/s", cores=os.cpu_count(), kind="port",
+                sample=f"CPU oracle (dequant + fp32 matmul, scalar attention; OpenMP over {os.cpu_count()} cores) on 1 of "
+                f"{cfg['layers']} layers (4 int4 GEMMs + paged attention), batch {cpu_batch} x ctx {ctx}, scaled x{cfg['layers']}; "
+                f"sample took {t_total:.1f} s")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    from neuralmagic_vllm_amd import _custom_ops as ops
+    cfg = dict(LLAMA3_8B)
+    cfg["layers"] = args.layers
+    model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev)
+
+    model.step()  # eager once: allocates GEMM scratch outside capture
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model.step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            model.step()
+    run = graph.replay if graph is not None else model.step
+
+    for _ in range(args.warmup):
+        run()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    result = None
+    if rank == 0:
+        kb = kernel_breakdown(model)
+        per_step = {k: v["ms"] * v["launches"] for k, v in kb.items()}
+        dom = max(per_step, key=per_step.get)
+        d = kb[dom]
+        is_gemm = dom.startswith("int4_gemm")
+        # HBM-bound below the ridge (4*M flop/B vs ~312 flop/B machine balance)
+        hbm_bound = (not is_gemm) or (d["flops"] / d["bytes"] < MFMA_F16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9))
+        if hbm_bound:
+            roof = dict(bound="hbm", kernel=dom, achieved=round(d["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(d["gbs"] / HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(d["ms"] * 1e3, 2),
+                        algorithmic_bytes_per_launch=int(d["bytes"]))
+        else:
+            roof = dict(bound="mfma", kernel=dom, achieved=round(d["tflops"], 1), peak=MFMA_F16_PEAK_TF, unit="TFLOP/s",
+                        frac=round(d["tflops"] / MFMA_F16_PEAK_TF, 4), traffic=None, avg_launch_us=round(d["ms"] * 1e3, 2),
+                        algorithmic_flops_per_launch=float(d["flops"]))
+        result = {
+            "metric": "decode tokens/sec, Llama-3-8B GPTQ-int4 (Marlin-format) TP=1",
+            "value": round(value, 1),
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "Llama-3-8B GPTQ-int4 g128 decode step, TP=1 (configs[1])", "batch_per_gpu": args.batch,
+                       "context": args.ctx, "layers": args.layers, "kv_cache": "fp16 block 16", "hip_graph": graph is not None,
+                       "parallelism": f"dp{world} (independent TP=1 replicas)"},
+            "roofline": roof,
+            "kernels": {k: {"us": round(v["ms"] * 1e3, 2), "GBps": round(v["gbs"], 1), "TFLOPs": round(v["tflops"], 2),
+                            "step_share_ms": round(per_step[k], 3)} for k, v in kb.items()},
+            "hot_path_share_of_step": round(sum(per_step.values()) / ms_per_step, 3),
+        }
+        if args.sweep:
+            result["sweep"] = sweep(ops, cfg, dev)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.ctx)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def sweep(ops, cfg, dev):
+    """int4 GEMM table (4 Llama-3-8B shapes x M) — TFLOP/s and GB/s per launch."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    H, I = cfg["hidden"], cfg["inter"]
+    shapes = dict(qkv=(H, 6144), o=(4096, H), gate_up=(H, 2 * I), down=(I, H))
+    e = torch.empty(0, dtype=torch.int32, device=dev)
+    table = {}
+    for name, (K, N) in shapes.items():
+        ws = [random_marlin_weight(K, N, cfg["group"], dev, g) for _ in range(4)]
+        wsp = torch.zeros(N // 64 * 16, dtype=torch.int32, device=dev)
+        for M in (1, 8, 16, 32, 64, 128, 256, 512, 1024, 2048):
+            x = torch.randn(M, K, dtype=torch.float16, device=dev)
+
+            def run():
+                for w in ws:
+                    ops.gptq_marlin_gemm(x, w[0], w[1], e, e, wsp, 4, M, N, K, True)
+
+            run()
+            ms = time_events(run, 5) / len(ws)
+            table[f"{name}_M{M}"] = {"us": round(ms * 1e3, 2), "GBps": round(gemm_bytes(M, K, N, cfg["group"]) / ms / 1e6, 1),
+                                     "TFLOPs": round(2.0 * M * K * N / ms / 1e9, 2)}
+    return table
+
+
+if __name__ == "__main__":
+    main()
