@@ -5,10 +5,10 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (
   step      = one decode step of the whole batch through 32 decoder layers + lm_head:
               per layer RMSNorm -> int4 qkv GEMM -> RoPE -> reshape_and_cache -> paged_attention -> int4 o_proj GEMM
               -> RMSNorm(+residual) -> int4 gate_up GEMM -> SiLU*mul -> int4 down GEMM; then final norm, fp16 lm_head,
-              greedy argmax. The four int4 GEMMs, the KV write and the attention are this repo's HIP kernels called
-              through the C-ABI; the element-wise neighbours (RMSNorm / RoPE / SiLU, SURVEY §8f "next") and the fp16
-              lm_head run as plain torch ops. The step is captured in a HIP graph (the reference decodes under CUDA
-              graphs too: vllm/worker/model_runner.py:910-1111).
+              greedy argmax. Every per-layer op is one of this repo's HIP kernels called through the C-ABI; only the
+              embedding gather, the fp16 lm_head GEMM (hipBLASLt via torch.matmul: a plain library GEMM) and the argmax
+              are torch ops. The step is captured in a HIP graph (the reference decodes under CUDA graphs too:
+              vllm/worker/model_runner.py:910-1111).
   value     = decoded tokens / s over all ranks (each rank = an independent TP=1 replica: weak scaling).
   roofline  = the kernel class with the largest share of the step, timed with HIP events on the launch stream.
   cpu_baseline = the CPU oracle (a port: dequant + fp32 matmul, scalar attention) on a bounded sample, rank 0 only.
@@ -91,8 +91,8 @@ class Llama3Decode:
         self.slot_mapping = (self.block_tables[:, last // block_size].long() * block_size + last % block_size)
         self.positions = torch.full((batch, ), last, dtype=torch.long, device=device)
         inv_freq = 1.0 / (500000.0**(torch.arange(0, D, 2, device=device).float() / D))
-        ang = self.positions.float()[:, None] * inv_freq[None, :]
-        self.cos, self.sin = ang.cos()[:, None, :].half(), ang.sin()[:, None, :].half()
+        ang = torch.arange(ctx, device=device).float()[:, None] * inv_freq[None, :]
+        self.cos_sin_cache = torch.cat((ang.cos(), ang.sin()), dim=-1).half()  # [max_pos, rot_dim] (rotary_embedding.py)
         self.tokens = torch.randint(0, cfg["vocab"], (batch, ), generator=g, device=device)
         self.workspace = torch.zeros(max(N for _, N in self.shapes.values()) // 64 * 16, dtype=torch.int32, device=device)
         self.empty = torch.empty(0, dtype=torch.int32, device=device)
@@ -106,16 +106,6 @@ class Llama3Decode:
             self.max_logits = torch.empty(batch, nh, self.P, dtype=torch.float32, device=device)
         self.next_tokens = torch.zeros(batch, dtype=torch.long, device=device)
 
-    # -- caller-side element-wise neighbours (plain torch; out of the hot-path scope for now) --
-    @staticmethod
-    def rms_norm(x, w, eps=1e-5):
-        xf = x.float()
-        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype) * w
-
-    def rope(self, x):  # x [B, heads, D], NeoX style
-        x1, x2 = x[..., :x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
-        return torch.cat((x1 * self.cos - x2 * self.sin, x2 * self.cos + x1 * self.sin), dim=-1)
-
     def gemm(self, x, w, name):
         K, N = self.shapes[name]
         return self.ops.gptq_marlin_gemm(x, w[0], w[1], self.empty, self.empty, self.workspace, 4, x.shape[0], N, K, True)
@@ -123,7 +113,7 @@ class Llama3Decode:
     def attention(self, q, layer):
         cfg = self.cfg
         kc, vc = self.kv[layer]
-        out = torch.empty_like(q)
+        out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
         if self.use_v1:
             self.ops.paged_attention_v1(out, q, kc, vc, cfg["kv_heads"], self.scale, self.block_tables, self.seq_lens,
                                         self.BS, self.L, None, "auto", 1.0)
@@ -133,32 +123,35 @@ class Llama3Decode:
         return out
 
     def step(self):
-        cfg = self.cfg
+        """Same op sequence as the reference's LlamaDecoderLayer (vllm/model_executor/models/llama.py:154-230):
+        fused_add_rms_norm -> qkv -> rotary_embedding (in place) -> reshape_and_cache -> paged_attention -> o_proj ->
+        fused_add_rms_norm -> gate_up -> silu_and_mul -> down."""
+        cfg, ops = self.cfg, self.ops
         nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
         h = self.embed[self.tokens]
         resid = None
         for li, lw in enumerate(self.layers):
             if resid is None:
                 resid = h
+                x = torch.empty_like(h)
+                ops.rms_norm(x, h, lw["ln1"], 1e-5)
             else:
-                resid = resid + h
-            x = self.rms_norm(resid, lw["ln1"])
+                ops.fused_add_rms_norm(h, resid, lw["ln1"], 1e-5)
+                x = h
             qkv = self.gemm(x, lw["qkv"], "qkv")
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-            q = self.rope(q.reshape(-1, nh, D))
-            k = self.rope(k.reshape(-1, nkv, D))
-            v = v.reshape(-1, nkv, D)
+            ops.rotary_embedding(self.positions, q, k, D, self.cos_sin_cache, True)
             kc, vc = self.kv[li]
-            self.ops.reshape_and_cache(k, v, kc, vc, self.slot_mapping, "auto", 1.0)
-            a = self.attention(q.contiguous(), li)
-            h = self.gemm(a.reshape(-1, nh * D), lw["o"], "o")
-            resid = resid + h
-            x = self.rms_norm(resid, lw["ln2"])
-            gu = self.gemm(x, lw["gate_up"], "gate_up")
-            act = torch.nn.functional.silu(gu[:, :cfg["inter"]]) * gu[:, cfg["inter"]:]
+            ops.reshape_and_cache(k.view(-1, nkv, D), v.view(-1, nkv, D), kc, vc, self.slot_mapping, "auto", 1.0)
+            a = self.attention(q.view(-1, nh, D), li)
+            h = self.gemm(a.view(-1, nh * D), lw["o"], "o")
+            ops.fused_add_rms_norm(h, resid, lw["ln2"], 1e-5)
+            gu = self.gemm(h, lw["gate_up"], "gate_up")
+            act = torch.empty(gu.shape[0], cfg["inter"], dtype=gu.dtype, device=gu.device)
+            ops.silu_and_mul(act, gu)
             h = self.gemm(act, lw["down"], "down")
-        x = self.rms_norm(resid + h, self.final_ln)
-        logits = torch.matmul(x, self.lm_head.t())
+        ops.fused_add_rms_norm(h, resid, self.final_ln, 1e-5)
+        logits = torch.matmul(h, self.lm_head.t())
         self.next_tokens.copy_(logits.argmax(-1))
         return self.next_tokens
 

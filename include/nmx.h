@@ -139,6 +139,30 @@ int nmx_fp8_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_
                         int size_n, int size_k, int dtype, nmx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Element-wise neighbours of the GEMMs on the decode path.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* rms_norm (csrc/layernorm_kernels.cu:293-312): out = scalar(x * rsqrt(mean(x^2) + eps)) * weight, rows contiguous. */
+int nmx_rms_norm(void* out, const void* input, const void* weight, float epsilon, int num_tokens, int hidden_size,
+                 int dtype, nmx_stream_t stream);
+/* fused_add_rms_norm (csrc/layernorm_kernels.cu:327-352): residual += input (in place), input = rms_norm(residual). */
+int nmx_fused_add_rms_norm(void* input, void* residual, const void* weight, float epsilon, int num_tokens,
+                           int hidden_size, int dtype, nmx_stream_t stream);
+/* rotary_embedding / batched_rotary_embedding (csrc/pos_encoding_kernels.cu:124-203). In place on query / key
+ * ([num_tokens, heads * head_size], row strides in elements). cos_sin_cache [max_pos, rot_dim];
+ * cos_sin_cache_offsets [num_tokens] int64 or NULL (plain rotary_embedding). */
+int nmx_rotary_embedding(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
+                         const int64_t* cos_sin_cache_offsets, int rot_dim, int64_t query_stride, int64_t key_stride,
+                         int num_tokens, int num_heads, int num_kv_heads, int head_size, int is_neox, int dtype,
+                         nmx_stream_t stream);
+/* activation codes for nmx_act_and_mul / nmx_activation (csrc/activation_kernels.cu) */
+enum { NMX_ACT_SILU = 0, NMX_ACT_GELU = 1, NMX_ACT_GELU_TANH = 2, NMX_ACT_GELU_NEW = 3, NMX_ACT_GELU_FAST = 4,
+       NMX_ACT_GELU_QUICK = 5 };
+/* silu_and_mul / gelu_and_mul / gelu_tanh_and_mul: out [T, d] = ACT(in[T, :d]) * in[T, d:] */
+int nmx_act_and_mul(void* out, const void* input, int num_tokens, int d, int act, int dtype, nmx_stream_t stream);
+/* gelu_new / gelu_fast / gelu_quick: out [T, d] = ACT(in [T, d]) */
+int nmx_activation(void* out, const void* input, int num_tokens, int d, int act, int dtype, nmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Device utilities (csrc/cuda_utils_kernels.cu).
  * ---------------------------------------------------------------------------------------------------------- */
 int nmx_get_max_shared_memory_per_block_device_attribute(int device, int* value);

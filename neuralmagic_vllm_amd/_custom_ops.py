@@ -78,6 +78,94 @@ def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------------
+# activation / norm / rotary ops (vllm/_custom_ops.py:48-163)
+# ---------------------------------------------------------------------------------------------------------
+_ACT = {"silu": 0, "gelu": 1, "gelu_tanh": 2, "gelu_new": 3, "gelu_fast": 4, "gelu_quick": 5}
+
+
+def _gated(out: torch.Tensor, x: torch.Tensor, kind: str) -> None:
+    _dev(x)
+    d = x.shape[-1] // 2
+    if not (x.is_contiguous() and out.is_contiguous()) or out.shape[-1] != d:
+        raise RuntimeError("act_and_mul: out [..., d] and input [..., 2 * d] must be contiguous")
+    _lib.check(_lib.lib().nmx_act_and_mul(_p(out), _p(x), c_int(x.numel() // x.shape[-1]), c_int(d), c_int(_ACT[kind]),
+                                          c_int(_dt(x)), _stream(x)))
+
+
+def _plain_act(out: torch.Tensor, x: torch.Tensor, kind: str) -> None:
+    _dev(x)
+    d = x.shape[-1]
+    if not (x.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("activation: out and input must be contiguous")
+    _lib.check(_lib.lib().nmx_activation(_p(out), _p(x), c_int(x.numel() // d), c_int(d), c_int(_ACT[kind]),
+                                         c_int(_dt(x)), _stream(x)))
+
+
+def silu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    _gated(out, x, "silu")
+
+
+def gelu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    _gated(out, x, "gelu")
+
+
+def gelu_tanh_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    _gated(out, x, "gelu_tanh")
+
+
+def gelu_fast(out: torch.Tensor, x: torch.Tensor) -> None:
+    _plain_act(out, x, "gelu_fast")
+
+
+def gelu_new(out: torch.Tensor, x: torch.Tensor) -> None:
+    _plain_act(out, x, "gelu_new")
+
+
+def gelu_quick(out: torch.Tensor, x: torch.Tensor) -> None:
+    _plain_act(out, x, "gelu_quick")
+
+
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    _dev(query)
+    num_tokens = query.numel() // query.shape[-1]
+    _lib.check(_lib.lib().nmx_rotary_embedding(
+        _p(positions), _p(query), _p(key), _p(cos_sin_cache), c_vp(0), c_int(cos_sin_cache.shape[1]),
+        c_i64(query.stride(-2)), c_i64(key.stride(-2)), c_int(num_tokens), c_int(query.shape[-1] // head_size),
+        c_int(key.shape[-1] // head_size), c_int(head_size), c_int(int(is_neox)), c_int(_dt(query)), _stream(query)))
+
+
+def batched_rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                             cos_sin_cache: torch.Tensor, is_neox: bool, rot_dim: int,
+                             cos_sin_cache_offsets: torch.Tensor) -> None:
+    _dev(query)
+    num_tokens = cos_sin_cache_offsets.shape[0]
+    _lib.check(_lib.lib().nmx_rotary_embedding(
+        _p(positions), _p(query), _p(key), _p(cos_sin_cache), _p(cos_sin_cache_offsets), c_int(rot_dim),
+        c_i64(query.stride(-2)), c_i64(key.stride(-2)), c_int(num_tokens), c_int(query.shape[-1] // head_size),
+        c_int(key.shape[-1] // head_size), c_int(head_size), c_int(int(is_neox)), c_int(_dt(query)), _stream(query)))
+
+
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+    _dev(input)
+    hidden = input.shape[-1]
+    if not (input.is_contiguous() and out.is_contiguous() and weight.is_contiguous()):
+        raise RuntimeError("rms_norm: tensors must be contiguous")
+    _lib.check(_lib.lib().nmx_rms_norm(_p(out), _p(input), _p(weight), c_f(epsilon), c_int(input.numel() // hidden),
+                                       c_int(hidden), c_int(_dt(input)), _stream(input)))
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+    _dev(input)
+    hidden = input.shape[-1]
+    if not (input.is_contiguous() and residual.is_contiguous() and weight.is_contiguous()):
+        raise RuntimeError("fused_add_rms_norm: tensors must be contiguous")
+    _lib.check(_lib.lib().nmx_fused_add_rms_norm(_p(input), _p(residual), _p(weight), c_f(epsilon),
+                                                 c_int(input.numel() // hidden), c_int(hidden), c_int(_dt(input)),
+                                                 _stream(input)))
+
+
+# ---------------------------------------------------------------------------------------------------------
 # paged attention (vllm/_custom_ops.py:73-129)
 # ---------------------------------------------------------------------------------------------------------
 def _attn_common(fn, head_args, query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,

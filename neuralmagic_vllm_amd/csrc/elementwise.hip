@@ -1,0 +1,292 @@
+// Element-wise neighbours of the hot GEMMs on the decode path: RMSNorm (+ fused residual add), rotary embedding,
+// gated activations. Replaces csrc/layernorm_kernels.cu, csrc/pos_encoding_kernels.cu, csrc/activation_kernels.cu of
+// the reference. One workgroup per token; 16-byte vector loads wherever the row allows it.
+// Rounding follows the reference's scalar_t arithmetic step by step (every scalar_t operation rounds to scalar_t),
+// so results are bit-comparable with the CPU oracle.
+#include "nmx_common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  float t = (threadIdx.x < nw) ? smem[threadIdx.x] : 0.f;
+  if (wave == 0) {
+    t = wave_reduce_sum(t);
+    if (lane == 0) smem[16] = t;
+  }
+  __syncthreads();
+  return smem[16];
+}
+
+template <typename T> __device__ __forceinline__ T rnd_mul(T a, T b) {  // scalar_t * scalar_t -> scalar_t
+  return Scalar<T>::from_f32(Scalar<T>::to_f32(a) * Scalar<T>::to_f32(b));
+}
+
+// rms_norm (layernorm_kernels.cu:22-46): out = scalar_t(x * rsqrt(mean(x^2) + eps)) * weight
+// fused_add_rms_norm (:258-291): z = input + residual (scalar_t); residual = z; input = scalar_t(z * s) * weight
+template <typename T, bool FUSED_ADD>
+__global__ void rms_norm_kernel(T* __restrict__ out, T* __restrict__ input, T* __restrict__ residual,
+                                const T* __restrict__ weight, float eps, int hidden) {
+  __shared__ float smem[17];
+  const int64_t row = (int64_t)blockIdx.x * hidden;
+  float var = 0.f;
+  for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+    T x = input[row + i];
+    if constexpr (FUSED_ADD) {
+      x = Scalar<T>::from_f32(Scalar<T>::to_f32(x) + Scalar<T>::to_f32(residual[row + i]));
+      residual[row + i] = x;
+    }
+    const float f = Scalar<T>::to_f32(x);
+    var += f * f;
+  }
+  var = block_sum(var, smem);
+  const float s = rsqrtf(var / (float)hidden + eps);
+  for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+    const T x = FUSED_ADD ? residual[row + i] : input[row + i];
+    const T n = Scalar<T>::from_f32(Scalar<T>::to_f32(x) * s);
+    out[row + i] = rnd_mul<T>(n, weight[i]);
+  }
+}
+
+// 16-B vectorised fp16 / bf16 variant (hidden % 8 == 0, 16-B aligned rows), one pass over registers
+template <typename T, bool FUSED_ADD, int VPT>  // VPT = 16-B vectors per thread
+__global__ void rms_norm_vec_kernel(T* __restrict__ out, T* __restrict__ input, T* __restrict__ residual,
+                                    const T* __restrict__ weight, float eps, int hidden) {
+  __shared__ float smem[17];
+  const int64_t row = (int64_t)blockIdx.x * hidden;
+  const int nvec = hidden / 8;
+  union V { u32x4 u; T e[8]; };
+  V x[VPT];
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = threadIdx.x + k * blockDim.x;
+    if (v < nvec) {
+      x[k].u = *reinterpret_cast<const u32x4*>(input + row + v * 8);
+      if constexpr (FUSED_ADD) {
+        V r;
+        r.u = *reinterpret_cast<const u32x4*>(residual + row + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[k].e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) + Scalar<T>::to_f32(r.e[j]));
+        *reinterpret_cast<u32x4*>(residual + row + v * 8) = x[k].u;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = Scalar<T>::to_f32(x[k].e[j]);
+        var += f * f;
+      }
+    }
+  }
+  var = block_sum(var, smem);
+  const float s = rsqrtf(var / (float)hidden + eps);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = threadIdx.x + k * blockDim.x;
+    if (v < nvec) {
+      V w, o;
+      w.u = *reinterpret_cast<const u32x4*>(weight + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * s), w.e[j]);
+      *reinterpret_cast<u32x4*>(out + row + v * 8) = o.u;
+    }
+  }
+}
+
+// rotary embedding (pos_encoding_kernels.cu:10-96): in place on query / key, NeoX or GPT-J pairing.
+// arr[x] = x * cos - y * sin ; arr[y] = y * cos + x * sin, every operation rounded to scalar_t.
+template <typename T, bool NEOX>
+__global__ void rotary_kernel(const int64_t* __restrict__ positions, T* __restrict__ query, T* __restrict__ key,
+                              const T* __restrict__ cos_sin_cache, const int64_t* __restrict__ offsets, int rot_dim,
+                              int64_t q_stride, int64_t k_stride, int num_heads, int num_kv_heads, int head_size) {
+  const int64_t tok = blockIdx.x;
+  int64_t pos = positions[tok];
+  if (offsets != nullptr) pos += offsets[tok];
+  const T* cache = cos_sin_cache + pos * rot_dim;
+  const int embed = rot_dim / 2;
+  const int nq = num_heads * embed, nk = num_kv_heads * embed;
+  for (int i = threadIdx.x; i < nq + nk; i += blockDim.x) {
+    const bool is_q = i < nq;
+    const int ii = is_q ? i : i - nq;
+    const int head = ii / embed, ro = ii % embed;
+    T* arr = (is_q ? query + tok * q_stride : key + tok * k_stride) + (int64_t)head * head_size;
+    const int xi = NEOX ? ro : 2 * ro;
+    const int yi = NEOX ? embed + ro : 2 * ro + 1;
+    const T c = cache[ro], s = cache[embed + ro];
+    const T x = arr[xi], y = arr[yi];
+    arr[xi] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(x, c)) - Scalar<T>::to_f32(rnd_mul<T>(y, s)));
+    arr[yi] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(y, c)) + Scalar<T>::to_f32(rnd_mul<T>(x, s)));
+  }
+}
+
+enum { ACT_SILU = 0, ACT_GELU = 1, ACT_GELU_TANH = 2, ACT_GELU_NEW = 3, ACT_GELU_FAST = 4, ACT_GELU_QUICK = 5 };
+
+template <typename T, int ACT>
+__device__ __forceinline__ T act_fn(T xv) {
+  const float f = Scalar<T>::to_f32(xv);
+  if constexpr (ACT == ACT_SILU) {
+    return Scalar<T>::from_f32(f / (1.0f + expf(-f)));  // activation_kernels.cu:27-30
+  } else if constexpr (ACT == ACT_GELU) {
+    return Scalar<T>::from_f32(f * 0.5f * (1.0f + erff(f * 0.70710678118654752440f)));  // :33-40
+  } else if constexpr (ACT == ACT_GELU_TANH) {
+    const float beta = 1.41421356237309504880f * 1.12837916709551257390f * 0.5f;  // :43-53
+    const float inner = beta * (f + 0.044715f * (f * f * f));
+    return Scalar<T>::from_f32(0.5f * f * (1.0f + tanhf(inner)));
+  } else if constexpr (ACT == ACT_GELU_NEW) {  // :113-118, scalar_t arithmetic step by step
+    const T x3t = rnd_mul<T>(rnd_mul<T>(xv, xv), xv);
+    const float x3 = Scalar<T>::to_f32(x3t);
+    const T inner = Scalar<T>::from_f32(f + Scalar<T>::to_f32(Scalar<T>::from_f32(0.044715f * x3)));
+    const T t = Scalar<T>::from_f32(tanhf(Scalar<T>::to_f32(Scalar<T>::from_f32(0.79788456f * Scalar<T>::to_f32(inner)))));
+    const T half_x = rnd_mul<T>(Scalar<T>::from_f32(0.5f), xv);
+    const T one_t = Scalar<T>::from_f32(1.0f + Scalar<T>::to_f32(t));
+    return rnd_mul<T>(half_x, one_t);
+  } else if constexpr (ACT == ACT_GELU_FAST) {  // :121-127
+    const T a = Scalar<T>::from_f32(f * 0.79788456f);
+    const T b = Scalar<T>::from_f32(1.0f + Scalar<T>::to_f32(rnd_mul<T>(Scalar<T>::from_f32(0.044715f * f), xv)));
+    const T t = Scalar<T>::from_f32(tanhf(Scalar<T>::to_f32(rnd_mul<T>(a, b))));
+    const T half_x = rnd_mul<T>(Scalar<T>::from_f32(0.5f), xv);
+    const T one_t = Scalar<T>::from_f32(1.0f + Scalar<T>::to_f32(t));
+    return rnd_mul<T>(half_x, one_t);
+  } else {
+    return Scalar<T>::from_f32(f / (1.0f + expf(-1.702f * f)));  // :130-133
+  }
+}
+
+// act_and_mul (activation_kernels.cu:12-24): out[t, i] = ACT(in[t, i]) * in[t, d + i]
+template <typename T, int ACT>
+__global__ void act_and_mul_kernel(T* __restrict__ out, const T* __restrict__ in, int d) {
+  const int64_t tok = blockIdx.x;
+  const T* x = in + tok * 2 * d;
+  if constexpr (sizeof(T) == 2) {
+    if ((d & 7) == 0) {
+      union V { u32x4 u; T e[8]; };
+      for (int v = threadIdx.x; v < d / 8; v += blockDim.x) {
+        V a, b, o;
+        a.u = *reinterpret_cast<const u32x4*>(x + v * 8);
+        b.u = *reinterpret_cast<const u32x4*>(x + d + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(act_fn<T, ACT>(a.e[j]), b.e[j]);
+        *reinterpret_cast<u32x4*>(out + tok * d + v * 8) = o.u;
+      }
+      return;
+    }
+  }
+  for (int i = threadIdx.x; i < d; i += blockDim.x) out[tok * d + i] = rnd_mul<T>(act_fn<T, ACT>(x[i]), x[d + i]);
+}
+
+template <typename T, int ACT>
+__global__ void activation_kernel(T* __restrict__ out, const T* __restrict__ in, int d) {
+  const int64_t tok = blockIdx.x;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) out[tok * d + i] = act_fn<T, ACT>(in[tok * d + i]);
+}
+
+template <typename T>
+int launch_rms(void* out, void* input, void* residual, const void* weight, float eps, int num_tokens, int hidden,
+               bool fused, hipStream_t stream) {
+  const bool vec = sizeof(T) == 2 && hidden % 8 == 0 &&
+                   (((uintptr_t)out | (uintptr_t)input | (uintptr_t)weight | (uintptr_t)residual) % 16 == 0) &&
+                   hidden / 8 <= 1024 * 2;
+  if (vec) {
+    const int nvec = hidden / 8;
+    int threads = std::min(1024, ((nvec + 63) / 64) * 64);
+    if (nvec > 256 && nvec <= 2048) threads = std::min(1024, ((nvec / 2 + 63) / 64) * 64);  // 2 vectors per thread
+    const int vpt = (nvec + threads - 1) / threads;
+#define NMX_RMS(F, V) rms_norm_vec_kernel<T, F, V><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden)
+    if (fused) { if (vpt == 1) NMX_RMS(true, 1); else NMX_RMS(true, 2); }
+    else { if (vpt == 1) NMX_RMS(false, 1); else NMX_RMS(false, 2); }
+#undef NMX_RMS
+  } else {
+    const int threads = std::min(1024, ((hidden + 63) / 64) * 64);
+    if (fused) rms_norm_kernel<T, true><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden);
+    else rms_norm_kernel<T, false><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden);
+  }
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+template <typename T>
+int launch_act(void* out, const void* in, int num_tokens, int d, int act, bool gated, hipStream_t stream) {
+  const int work = (gated && sizeof(T) == 2 && d % 8 == 0) ? d / 8 : d;
+  const int threads = std::min(1024, std::max(64, ((work + 63) / 64) * 64));
+#define NMX_ACT(A)                                                                                      \
+  if (gated) act_and_mul_kernel<T, A><<<num_tokens, threads, 0, stream>>>((T*)out, (const T*)in, d);    \
+  else activation_kernel<T, A><<<num_tokens, threads, 0, stream>>>((T*)out, (const T*)in, d)
+  switch (act) {
+    case ACT_SILU: NMX_ACT(ACT_SILU); break;
+    case ACT_GELU: NMX_ACT(ACT_GELU); break;
+    case ACT_GELU_TANH: NMX_ACT(ACT_GELU_TANH); break;
+    case ACT_GELU_NEW: NMX_ACT(ACT_GELU_NEW); break;
+    case ACT_GELU_FAST: NMX_ACT(ACT_GELU_FAST); break;
+    case ACT_GELU_QUICK: NMX_ACT(ACT_GELU_QUICK); break;
+    default: NMX_CHECK(false, NMX_ERR_INVALID_ARG, "unknown activation %d", act);
+  }
+#undef NMX_ACT
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+}  // namespace
+
+#define NMX_DISPATCH_DT(dtype, CALL)                                                     \
+  switch (dtype) {                                                                       \
+    case NMX_F32: { using T = float; return CALL; }                                      \
+    case NMX_F16: { using T = f16; return CALL; }                                        \
+    case NMX_BF16: { using T = bf16; return CALL; }                                      \
+    default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "unsupported dtype code %d", dtype);  \
+  }
+
+extern "C" int nmx_rms_norm(void* out, const void* input, const void* weight, float epsilon, int num_tokens,
+                            int hidden_size, int dtype, nmx_stream_t stream) {
+  if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK(hidden_size > 0, NMX_ERR_INVALID_ARG, "hidden_size must be > 0");
+  NMX_DISPATCH_DT(dtype, launch_rms<T>(out, const_cast<void*>(input), nullptr, weight, epsilon, num_tokens, hidden_size, false, (hipStream_t)stream));
+}
+
+extern "C" int nmx_fused_add_rms_norm(void* input, void* residual, const void* weight, float epsilon, int num_tokens,
+                                      int hidden_size, int dtype, nmx_stream_t stream) {
+  if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK(hidden_size > 0, NMX_ERR_INVALID_ARG, "hidden_size must be > 0");
+  NMX_DISPATCH_DT(dtype, launch_rms<T>(input, input, residual, weight, epsilon, num_tokens, hidden_size, true, (hipStream_t)stream));
+}
+
+template <typename T>
+static int launch_rotary(const int64_t* positions, void* query, void* key, const void* cache, const int64_t* offsets,
+                         int rot_dim, int64_t q_stride, int64_t k_stride, int num_tokens, int num_heads,
+                         int num_kv_heads, int head_size, int is_neox, hipStream_t stream) {
+  const int work = (num_heads + num_kv_heads) * rot_dim / 2;
+  const int threads = std::min(512, std::max(64, ((work + 63) / 64) * 64));
+  if (is_neox)
+    rotary_kernel<T, true><<<num_tokens, threads, 0, stream>>>(positions, (T*)query, (T*)key, (const T*)cache, offsets, rot_dim,
+                                                               q_stride, k_stride, num_heads, num_kv_heads, head_size);
+  else
+    rotary_kernel<T, false><<<num_tokens, threads, 0, stream>>>(positions, (T*)query, (T*)key, (const T*)cache, offsets, rot_dim,
+                                                                q_stride, k_stride, num_heads, num_kv_heads, head_size);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+extern "C" int nmx_rotary_embedding(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
+                                    const int64_t* cos_sin_cache_offsets, int rot_dim, int64_t query_stride,
+                                    int64_t key_stride, int num_tokens, int num_heads, int num_kv_heads,
+                                    int head_size, int is_neox, int dtype, nmx_stream_t stream) {
+  if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, NMX_ERR_INVALID_ARG,
+            "rot_dim = %d must be even and <= head_size = %d", rot_dim, head_size);
+  NMX_DISPATCH_DT(dtype, launch_rotary<T>(positions, query, key, cos_sin_cache, cos_sin_cache_offsets, rot_dim, query_stride,
+                                          key_stride, num_tokens, num_heads, num_kv_heads, head_size, is_neox, (hipStream_t)stream));
+}
+
+extern "C" int nmx_act_and_mul(void* out, const void* input, int num_tokens, int d, int act, int dtype,
+                               nmx_stream_t stream) {
+  if (num_tokens == 0 || d == 0) return NMX_OK;
+  NMX_DISPATCH_DT(dtype, launch_act<T>(out, input, num_tokens, d, act, true, (hipStream_t)stream));
+}
+
+extern "C" int nmx_activation(void* out, const void* input, int num_tokens, int d, int act, int dtype,
+                              nmx_stream_t stream) {
+  if (num_tokens == 0 || d == 0) return NMX_OK;
+  NMX_DISPATCH_DT(dtype, launch_act<T>(out, input, num_tokens, d, act, false, (hipStream_t)stream));
+}

@@ -22,7 +22,8 @@ DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with g++ (seconds). Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_attn_cache.cpp", "oracle_quant.cpp", "numfmt.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_attn_cache.cpp", "oracle_quant.cpp", "oracle_elementwise.cpp",
+                                             "numfmt.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -272,3 +273,41 @@ def scaled_mm(a, b, scale_a, scale_b, out_dtype, bias=None):
                         _p(bias.to(out_dtype).contiguous() if bias is not None else None), c_int(M), c_int(N),
                         c_int(K), c_int(int(is_fp8)), c_int(DT[out_dtype]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# element-wise neighbours (reference: csrc/layernorm_kernels.cu, pos_encoding_kernels.cu, activation_kernels.cu)
+# ---------------------------------------------------------------------------------------------
+def rms_norm(out, input, weight, epsilon) -> None:
+    hidden = input.shape[-1]
+    lib().orc_rms_norm(_p(out), _p(input), _p(None), _p(weight), c_f(epsilon), c_int(input.numel() // hidden),
+                       c_int(hidden), c_int(DT[input.dtype]), c_int(0))
+
+
+def fused_add_rms_norm(input, residual, weight, epsilon) -> None:
+    hidden = input.shape[-1]
+    lib().orc_rms_norm(_p(input), _p(input), _p(residual), _p(weight), c_f(epsilon), c_int(input.numel() // hidden),
+                       c_int(hidden), c_int(DT[input.dtype]), c_int(1))
+
+
+def rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox, cos_sin_cache_offsets=None) -> None:
+    num_tokens = query.numel() // query.shape[-1]
+    lib().orc_rotary_embedding(_p(positions), _p(query), _p(key), _p(cos_sin_cache), _p(cos_sin_cache_offsets),
+                               c_int(cos_sin_cache.shape[1]), c_i64(query.stride(-2)), c_i64(key.stride(-2)),
+                               c_int(num_tokens), c_int(query.shape[-1] // head_size), c_int(key.shape[-1] // head_size),
+                               c_int(head_size), c_int(int(is_neox)), c_int(DT[query.dtype]))
+
+
+_ACT = {"silu": 0, "gelu": 1, "gelu_tanh": 2, "gelu_new": 3, "gelu_fast": 4, "gelu_quick": 5}
+
+
+def act_and_mul(out, x, kind: str) -> None:
+    d = x.shape[-1] // 2
+    lib().orc_activation(_p(out), _p(x), c_int(x.numel() // x.shape[-1]), c_int(d), c_int(_ACT[kind]), c_int(1),
+                         c_int(DT[x.dtype]))
+
+
+def activation(out, x, kind: str) -> None:
+    d = x.shape[-1]
+    lib().orc_activation(_p(out), _p(x), c_int(x.numel() // d), c_int(d), c_int(_ACT[kind]), c_int(0),
+                         c_int(DT[x.dtype]))

@@ -193,6 +193,56 @@ def gen_quant():
         print("wrote", name)
 
 
+def gen_elementwise():
+    """rms_norm / fused_add_rms_norm / rotary_embedding / gated activations from the reference CPU backend
+    (csrc/cpu/{layernorm,pos_encoding,activation}.cpp; schema csrc/cpu/torch_bindings.cpp:39-99)."""
+    from oracle import build_ref
+    assert build_ref.build() and build_ref.load()
+    ops = torch.ops.nmref_cpu
+    torch.manual_seed(5)
+    d = {}
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        T, H = 5, 512
+        x = torch.randn(T, H, dtype=dtype)
+        res = torch.randn(T, H, dtype=dtype)
+        w = torch.randn(H, dtype=dtype)
+        out = torch.empty_like(x)
+        ops.rms_norm(out, x, w, 1e-5)
+        x2, r2 = x.clone(), res.clone()
+        ops.fused_add_rms_norm(x2, r2, w, 1e-5)
+        d.update({f"rms_x_{tag}": bits(x), f"rms_res_{tag}": bits(res), f"rms_w_{tag}": bits(w), f"rms_out_{tag}": bits(out),
+                  f"fused_out_{tag}": bits(x2), f"fused_res_{tag}": bits(r2)})
+        # rotary: 6 heads / 2 kv heads x 64, rot_dim 64 (neox) and 32 (gptj, partial)
+        for neox, rot in ((True, 64), (False, 32)):
+            pos = torch.tensor([0, 3, 17, 100, 255], dtype=torch.int64)
+            q = torch.randn(T, 6 * 64, dtype=dtype)
+            k = torch.randn(T, 2 * 64, dtype=dtype)
+            cache = torch.randn(256, rot, dtype=dtype)
+            q2, k2 = q.clone(), k.clone()
+            ops.rotary_embedding(pos, q2, k2, 64, cache, neox)
+            key = f"rope_{'neox' if neox else 'gptj'}_{tag}"
+            d.update({key + "_pos": pos.numpy(), key + "_q": bits(q), key + "_k": bits(k), key + "_cache": bits(cache),
+                      key + "_qo": bits(q2), key + "_ko": bits(k2)})
+        g = torch.randn(T, 2 * 192, dtype=dtype)
+        for name in ("silu_and_mul", "gelu_and_mul", "gelu_tanh_and_mul"):
+            o = torch.empty(T, 192, dtype=dtype)
+            getattr(ops, name)(o, g)
+            d[f"{name}_{tag}"] = bits(o)
+        d[f"gate_in_{tag}"] = bits(g)
+        a = torch.randn(T, 192, dtype=dtype)
+        for name in ("gelu_new", "gelu_fast"):
+            o = torch.empty_like(a)
+            getattr(ops, name)(o, a)
+            d[f"{name}_{tag}"] = bits(o)
+        d[f"act_in_{tag}"] = bits(a)
+    np.savez_compressed(os.path.join(HERE, "elementwise.npz"), **d)
+    print("wrote elementwise")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "elementwise":
+        gen_elementwise()
+        sys.exit(0)
     gen_quant()
     gen_attention_cache()
+    gen_elementwise()
