@@ -496,6 +496,87 @@ def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.T
 
 
 # ---------------------------------------------------------------------------------------------------------
+# fp8 / int8 activation quantisation and the W8A8 scaled GEMM (vllm/_custom_ops.py:218-350)
+# ---------------------------------------------------------------------------------------------------------
+def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
+    return bool(_lib.lib().nmx_scaled_mm_supports_fp8(c_int(cuda_device_capability)))
+
+
+def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                      out_dtype: Type[torch.dtype], bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert (b.shape[0] % 16 == 0 and b.shape[1] % 16 == 0)
+    assert (out_dtype is torch.bfloat16 or out_dtype is torch.float16)
+    _dev(a)
+    m, n, k = a.shape[0], b.shape[1], a.shape[1]
+    # checks mirror csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:59-76
+    if not (a.dim() == 2 and b.dim() == 2 and a.size(1) == b.size(0)):
+        raise RuntimeError("cutlass_scaled_mm: a [M,K] and b [K,N] expected")
+    if a.stride(1) != 1:
+        raise RuntimeError("cutlass_scaled_mm: a must be row-major")
+    if b.stride(0) != 1:
+        raise RuntimeError("cutlass_scaled_mm: b must be column-major")
+    if a.dtype != b.dtype or a.dtype not in (torch.float8_e4m3fn, torch.int8):
+        raise RuntimeError("cutlass_scaled_mm: a and b must both be float8_e4m3fn or int8")
+    if not (scale_a.is_contiguous() and scale_b.is_contiguous()):
+        raise RuntimeError("cutlass_scaled_mm: scales must be contiguous")
+    if scale_a.dtype != torch.float32 or scale_b.dtype != torch.float32:
+        raise RuntimeError("cutlass_scaled_mm: scales must be float32")
+    if bias is not None and not (bias.numel() == n and bias.is_contiguous() and bias.dim() == 1 and bias.dtype == out_dtype):
+        raise RuntimeError("cutlass_scaled_mm: bias must be a contiguous [N] tensor of the output dtype")
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    _lib.check(_lib.lib().nmx_scaled_mm(_p(out), _p(a), _p(b), _p(scale_a), c_int(scale_a.numel()), _p(scale_b),
+                                        c_int(scale_b.numel()), _p(bias), c_int(m), c_int(n), c_int(k),
+                                        c_i64(a.stride(0)), c_i64(b.stride(1)), c_i64(out.stride(0)),
+                                        c_int(int(a.dtype == torch.float8_e4m3fn)), c_int(_dt(out)), _stream(a)))
+    return out
+
+
+def scaled_fp8_quant(
+    input: torch.Tensor,
+    scale: Optional[torch.Tensor] = None,
+    batch_dim_padding: Optional[int] = None,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Same contract as vllm/_custom_ops.py:284-320 (padding rows, if any, are left uninitialised)."""
+    _dev(input)
+    if batch_dim_padding:
+        shape = (max(batch_dim_padding, input.shape[0]), *input.shape[1:])
+        output = torch.empty(shape, device=input.device, dtype=torch.float8_e4m3fn)
+    else:
+        output = torch.empty_like(input, dtype=torch.float8_e4m3fn)
+    x = input if input.is_contiguous() else input.contiguous()
+    if scale is None:
+        scale = torch.zeros(1, device=input.device, dtype=torch.float32)
+        dynamic = 1
+    else:
+        dynamic = 0
+        if scale.dtype != torch.float32 or scale.numel() != 1:
+            raise RuntimeError("scaled_fp8_quant: scale must be a float32 scalar tensor")
+    _lib.check(_lib.lib().nmx_scaled_fp8_quant(_p(output), _p(x), _p(scale), c_i64(x.numel()), c_int(_dt(x)),
+                                               c_int(dynamic), _stream(x)))
+    return output, scale
+
+
+def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Same contract as vllm/_custom_ops.py:324-350."""
+    _dev(input)
+    if not input.is_contiguous():
+        raise RuntimeError("input must be contiguous")  # int8_quant_kernels.cu:78
+    output = torch.empty_like(input, dtype=torch.int8)
+    hidden = input.shape[-1]
+    tokens = input.numel() // hidden
+    if scale is not None:
+        if scale.numel() != 1 or scale.dtype != torch.float32:
+            raise RuntimeError("scale.numel() == 1 (float32) expected")
+        _lib.check(_lib.lib().nmx_scaled_int8_quant(_p(output), _p(input), _p(scale), c_int(tokens), c_int(hidden),
+                                                    c_int(_dt(input)), c_int(0), _stream(input)))
+        return output, scale
+    input_scales = torch.empty((tokens, 1), device=input.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nmx_scaled_int8_quant(_p(output), _p(input), _p(input_scales), c_int(tokens), c_int(hidden),
+                                                c_int(_dt(input)), c_int(1), _stream(input)))
+    return output, input_scales
+
+
+# ---------------------------------------------------------------------------------------------------------
 # device utilities (vllm/_custom_ops.py:415-422)
 # ---------------------------------------------------------------------------------------------------------
 def get_device_attribute(attribute: int, device: int) -> int:

@@ -48,8 +48,6 @@ __device__ __forceinline__ uint32_t and_or(uint32_t q, uint32_t mask, uint32_t m
   return r;
 }
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
 // raw buffer descriptor (wave-uniform): base, num_records = bytes, untyped dword access. Loads past `bytes` return 0.
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
   const uint64_t a = (uint64_t)p;

@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "../../include/nmx.h"
 
 // ---- error plumbing -------------------------------------------------------------------------------------
@@ -42,6 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define NMX_WAVE 64
 
