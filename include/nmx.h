@@ -139,6 +139,33 @@ int nmx_fp8_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_
                         int size_n, int size_k, int dtype, nmx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Zero-point int4 formats consumed as stored in the checkpoint: AWQ and GPTQ (exllama). fp16 only.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* scratch (bytes) for the split-K partial sums of nmx_awq_gemm / nmx_gptq_gemm */
+int64_t nmx_zp_gemm_scratch_bytes(int m, int n);
+/* awq_gemm (csrc/quantization/awq/gemm_kernels.cu:492-549): out [m, oc] = in_feats [m, k] . W,
+ * W[k, 8c+j] = (nib(kernel[k,c], o_j) - nib(zeros[k/G,c], o_j)) * scaling_factors[k/G, 8c+j], o = [0,4,1,5,2,6,3,7].
+ * kernel [k, oc/8], zeros [k/G, oc/8] int32, scaling_factors [k/G, oc] fp16. Argument order of the C++ op
+ * (csrc/ops.h:66-68): (in, kernel, scaling_factors, zeros, split_k) — split_k is a reference tuning knob, unused. */
+int nmx_awq_gemm(const void* in_feats, const int32_t* kernel, const void* scaling_factors, const int32_t* zeros,
+                 void* out, void* scratch, int64_t scratch_bytes, int m, int k, int oc, int group_size,
+                 nmx_stream_t stream);
+/* awq_dequantize (awq/gemm_kernels.cu:436-484): out [in_c, 8 * qout_c] fp16 */
+int nmx_awq_dequantize(const int32_t* kernel, const void* scaling_factors, const int32_t* zeros, void* out, int in_c,
+                       int qout_c, int group_size, nmx_stream_t stream);
+/* gptq_gemm (csrc/quantization/gptq/q_gemm.cu:1823-1848), 4-bit: c [m, n] = a [m, k] . W,
+ * W[k, n] = (q - (z + 1)) * scales[g(k), n]. qweight [k/8, n], qzeros [groups, n/8], scales [groups, n] fp16.
+ * use_exllama != 0: qweight went through nmx_gptq_shuffle and g_idx (if not NULL) is the row permutation applied
+ * there (vllm/model_executor/layers/quantization/gptq.py:212-222); else g_idx is the per-row group index or NULL. */
+int nmx_gptq_gemm(const void* a, const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                  const int32_t* g_idx, void* c, void* scratch, int64_t scratch_bytes, int m, int n, int k, int groups,
+                  int use_exllama, int bit, nmx_stream_t stream);
+/* gptq_shuffle (q_gemm.cu:1850-1858), 4-bit, in place. q_perm [size_k] or NULL; tmp: same size as q_weight, needed
+ * only with q_perm. */
+int nmx_gptq_shuffle(int32_t* q_weight, int32_t* tmp, const int32_t* q_perm, int size_k, int size_n, int bit,
+                     nmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Activation quantisation and the W8A8 scaled GEMM.
  * ---------------------------------------------------------------------------------------------------------- */
 /* static_scaled_fp8_quant / dynamic_scaled_fp8_quant (csrc/quantization/fp8/common.cu:129-165).

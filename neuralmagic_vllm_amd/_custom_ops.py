@@ -496,6 +496,95 @@ def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.T
 
 
 # ---------------------------------------------------------------------------------------------------------
+# AWQ / GPTQ (vllm/_custom_ops.py:166-191)
+# ---------------------------------------------------------------------------------------------------------
+def _zp_scratch(a: torch.Tensor, m: int, n: int) -> torch.Tensor:
+    return _get_scratch(a.device, int(_lib.lib().nmx_zp_gemm_scratch_bytes(c_int(m), c_int(n))))
+
+
+_lib_zp_init = False
+
+
+def _zp_lib():
+    global _lib_zp_init
+    lib = _lib.lib()
+    if not _lib_zp_init:
+        lib.nmx_zp_gemm_scratch_bytes.restype = ctypes.c_int64
+        _lib_zp_init = True
+    return lib
+
+
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, split_k_iters: int, thx: int,
+                   thy: int) -> torch.Tensor:
+    # csrc/quantization/awq/gemm_kernels.cu:436-484 (thx / thy / split_k_iters only shape the reference's launch)
+    _dev(qweight)
+    in_c, qout_c = qweight.shape
+    if scales.dtype != torch.float16:
+        raise RuntimeError("awq_dequantize: scaling factors must be float16")
+    out = torch.empty((in_c, qout_c * 8), dtype=scales.dtype, device=scales.device)
+    _lib.check(_lib.lib().nmx_awq_dequantize(_p(qweight), _p(scales), _p(zeros), _p(out), c_int(in_c), c_int(qout_c),
+                                             c_int(in_c // scales.shape[0]), _stream(qweight)))
+    return out
+
+
+def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+             split_k_iters: int) -> torch.Tensor:
+    """Positional order is what matters: the C++ op is (in, kernel, scaling_factors, zeros, split_k)
+    (csrc/ops.h:66-68) and the reference caller passes (x, qweight, scales, qzeros, pack_factor)
+    (awq.py:172) into these mis-named parameters. Both orders are accepted here (told apart by dtype)."""
+    _dev(input)
+    scaling_factors, zeros = (qzeros, scales) if qzeros.dtype == torch.float16 else (scales, qzeros)
+    if input.dtype != torch.float16 or scaling_factors.dtype != torch.float16:
+        raise RuntimeError("awq_gemm only supports float16")
+    m, k = input.shape
+    oc = qweight.shape[1] * 8
+    group_size = k // scaling_factors.shape[0]
+    out = torch.empty((m, oc), dtype=input.dtype, device=input.device)
+    x = input if input.is_contiguous() else input.contiguous()
+    scratch = _zp_scratch(input, m, oc) if m > 0 else None
+    _zp_lib()
+    _lib.check(_lib.lib().nmx_awq_gemm(_p(x), _p(qweight), _p(scaling_factors), _p(zeros), _p(out), _p(scratch),
+                                       c_i64(scratch.numel() if scratch is not None else 0), c_int(m), c_int(k),
+                                       c_int(oc), c_int(group_size), _stream(input)))
+    return out
+
+
+def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor, b_gptq_scales: torch.Tensor,
+              b_g_idx: torch.Tensor, use_exllama: bool, bit: int) -> torch.Tensor:
+    # csrc/quantization/gptq/q_gemm.cu:1823-1848
+    _dev(a)
+    if a.dtype != torch.float16:
+        raise RuntimeError("gptq_gemm only supports float16")
+    m, k = a.shape
+    n = b_q_weight.shape[1]
+    c = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    has_idx = (not b_g_idx.is_meta) and b_g_idx.numel() > 0
+    if has_idx and b_g_idx.dtype != torch.int32:
+        b_g_idx = b_g_idx.to(torch.int32)
+    x = a if a.is_contiguous() else a.contiguous()
+    scratch = _zp_scratch(a, m, n) if m > 0 else None
+    _zp_lib()
+    _lib.check(_lib.lib().nmx_gptq_gemm(_p(x), _p(b_q_weight), _p(b_gptq_qzeros), _p(b_gptq_scales),
+                                        _p(b_g_idx if has_idx else None), _p(c), _p(scratch),
+                                        c_i64(scratch.numel() if scratch is not None else 0), c_int(m), c_int(n),
+                                        c_int(k), c_int(b_gptq_qzeros.shape[0]), c_int(int(bool(use_exllama))),
+                                        c_int(bit), _stream(a)))
+    return c
+
+
+def gptq_shuffle(q_weight: torch.Tensor, q_perm: torch.Tensor, bit: int) -> None:
+    # csrc/quantization/gptq/q_gemm.cu:1850-1858 (in place)
+    _dev(q_weight)
+    has_perm = (not q_perm.is_meta) and q_perm.numel() > 0
+    if has_perm and q_perm.dtype != torch.int32:
+        q_perm = q_perm.to(torch.int32)
+    tmp = torch.empty_like(q_weight) if has_perm else None
+    _lib.check(_lib.lib().nmx_gptq_shuffle(_p(q_weight), _p(tmp), _p(q_perm if has_perm else None),
+                                           c_int(q_weight.shape[0] * 32 // bit), c_int(q_weight.shape[1]), c_int(bit),
+                                           _stream(q_weight)))
+
+
+# ---------------------------------------------------------------------------------------------------------
 # fp8 / int8 activation quantisation and the W8A8 scaled GEMM (vllm/_custom_ops.py:218-350)
 # ---------------------------------------------------------------------------------------------------------
 def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:

@@ -1,0 +1,138 @@
+"""GPU parity tests for the zero-point int4 formats: awq_gemm / awq_dequantize / gptq_gemm / gptq_shuffle.
+The reference has NO kernel-level test for these ops (parity unpinned); the oracle follows the formulas
+of awq/gemm_kernels.cu:367-431 and gptq/q_gemm.cu:1387-1417, and the expected GEMM is a.float() @ w_ref.float()."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import packing
+from util import compute_max_diff, seed_all
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+@pytest.mark.parametrize("m", [1, 7, 16, 17, 33, 100])
+@pytest.mark.parametrize("k,n", [(128, 128), (512, 384), (1024, 1280), (3584, 8192)])
+@pytest.mark.parametrize("group", [32, 128])
+def test_awq_gemm(ops, m, k, n, group):
+    if (k, n) == (3584, 8192) and m not in (1, 16):
+        pytest.skip("large shape covered at two batch sizes")
+    seed_all(0)
+    w = torch.randn(k, n)
+    a = torch.randn(m, k, dtype=torch.float16)
+    w_ref, qweight, qzeros, scales = packing.awq_quantize(w, group)
+    # both argument orders seen in the reference (awq.py:172 vs _custom_ops.py:175-177)
+    out = ops.awq_gemm(a.to(DEV), qweight.to(DEV), scales.to(DEV), qzeros.to(DEV), 8)
+    ref = a.float() @ w_ref.float()
+    assert compute_max_diff(out.cpu(), ref) < TOL
+    out2 = ops.awq_gemm(a.to(DEV), qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), 8)
+    assert torch.equal(out, out2)
+    orc = oracle.awq_gemm(a, qweight, scales, qzeros, 8)
+    assert compute_max_diff(out.cpu(), orc) < TOL
+
+
+@pytest.mark.parametrize("k,n,group", [(128, 64, 32), (512, 384, 128), (1024, 1280, 64)])
+def test_awq_dequantize(ops, k, n, group):
+    seed_all(1)
+    w = torch.randn(k, n)
+    w_ref, qweight, qzeros, scales = packing.awq_quantize(w, group)
+    out = ops.awq_dequantize(qweight.to(DEV), scales.to(DEV), qzeros.to(DEV), 0, 0, 0)
+    assert torch.equal(out.cpu().view(torch.int16), oracle.awq_dequantize(qweight, scales, qzeros).view(torch.int16))
+    assert torch.equal(out.cpu().view(torch.int16), w_ref.view(torch.int16))
+
+
+def test_awq_errors(ops):
+    a = torch.zeros(1, 64, dtype=torch.float16, device=DEV)
+    qw = torch.zeros(64, 4, dtype=torch.int32, device=DEV)  # OC = 32: not a multiple of 64
+    s = torch.zeros(2, 32, dtype=torch.float16, device=DEV)
+    z = torch.zeros(2, 4, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="OC is not multiple"):
+        ops.awq_gemm(a, qw, s, z, 8)
+
+
+def shuffle_ref(qweight: torch.Tensor, q_perm=None) -> torch.Tensor:
+    """numpy restatement of gptq_shuffle 4-bit (q_gemm.cu:1543-1553 + make_sequential :1602-1640)."""
+    w = qweight.numpy().astype(np.uint32)
+    K8, N = w.shape
+    nib = np.stack([(w >> (4 * i)) & 0xf for i in range(8)], axis=1).reshape(K8 * 8, N)  # [K, N] codes
+    if q_perm is not None:
+        nib = nib[q_perm.numpy().astype(np.int64)]
+    nib = nib.reshape(K8, 8, N)
+    order = [0, 2, 4, 6, 1, 3, 5, 7]  # nibble position p holds k = order[p]
+    out = np.zeros((K8, N), dtype=np.uint32)
+    for p_, kk in enumerate(order):
+        out |= nib[:, kk, :].astype(np.uint32) << (4 * p_)
+    return torch.from_numpy(out.astype(np.int32))
+
+
+@pytest.mark.parametrize("act_order", [False, True])
+def test_gptq_shuffle(ops, act_order):
+    seed_all(2)
+    K, N = 256, 192
+    qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32)
+    perm = torch.randperm(K).to(torch.int32) if act_order else torch.empty(0, dtype=torch.int32)
+    g = qw.clone().to(DEV)
+    ops.gptq_shuffle(g, perm.to(DEV), 4)
+    assert torch.equal(g.cpu(), shuffle_ref(qw, perm if act_order else None))
+
+
+@pytest.mark.parametrize("m", [1, 16, 17, 50, 64])
+@pytest.mark.parametrize("k,n", [(128, 64), (512, 384), (4096, 4096)])
+@pytest.mark.parametrize("group", [32, 128])
+@pytest.mark.parametrize("mode", ["exllama", "exllama_act_order", "plain", "plain_act_order"])
+def test_gptq_gemm(ops, m, k, n, group, mode):
+    if (k, n) == (4096, 4096) and m not in (1, 16):
+        pytest.skip("large shape covered at two batch sizes")
+    seed_all(3)
+    w = torch.randn(k, n)
+    a = torch.randn(m, k, dtype=torch.float16)
+    w_ref, qweight, qzeros, scales, g_idx = packing.gptq_quantize(w, 4, group)
+    ref = a.float() @ w_ref.float()
+    if mode == "exllama":
+        qg = qweight.clone().to(DEV)
+        ops.gptq_shuffle(qg, torch.empty(0, dtype=torch.int32, device=DEV), 4)
+        out = ops.gptq_gemm(a.to(DEV), qg, qzeros.to(DEV), scales.to(DEV), torch.empty(0, device=DEV), True, 4)
+    elif mode == "exllama_act_order":
+        # checkpoint with desc_act: rows in arbitrary group order; the layer sorts them (gptq.py:212-222)
+        perm = torch.randperm(k)
+        codes = oracle_codes(qweight)[perm]           # checkpoint row order
+        g_idx_ck = g_idx[perm].contiguous()
+        qweight_ck = packing.gptq_pack(codes, 4, k, n)
+        a_ck = a[:, perm].contiguous()                # activations in checkpoint order: same product
+        q_perm = torch.argsort(g_idx_ck).to(torch.int32)
+        qg = qweight_ck.to(DEV)
+        ops.gptq_shuffle(qg, q_perm.to(DEV), 4)
+        out = ops.gptq_gemm(a_ck.to(DEV), qg, qzeros.to(DEV), scales.to(DEV), q_perm.to(DEV), True, 4)
+    elif mode == "plain":
+        out = ops.gptq_gemm(a.to(DEV), qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), torch.empty(0, device=DEV), False, 4)
+    else:
+        perm = torch.randperm(k)
+        codes = oracle_codes(qweight)[perm]
+        g_idx_ck = g_idx[perm].contiguous()
+        qweight_ck = packing.gptq_pack(codes, 4, k, n)
+        a_ck = a[:, perm].contiguous()
+        out = ops.gptq_gemm(a_ck.to(DEV), qweight_ck.to(DEV), qzeros.to(DEV), scales.to(DEV), g_idx_ck.to(DEV), False, 4)
+        orc = oracle.gptq_gemm(a_ck, qweight_ck, qzeros, scales, g_idx_ck, 4)
+        assert compute_max_diff(out.cpu(), orc) < TOL
+    assert compute_max_diff(out.cpu(), ref) < TOL
+    if mode == "plain":
+        orc = oracle.gptq_gemm(a, qweight, qzeros, scales, None, 4)
+        assert compute_max_diff(out.cpu(), orc) < TOL
+
+
+def oracle_codes(qweight: torch.Tensor) -> torch.Tensor:
+    w = qweight.numpy().astype(np.uint32)
+    nib = np.stack([(w >> (4 * i)) & 0xf for i in range(8)], axis=1).reshape(w.shape[0] * 8, w.shape[1])
+    return torch.from_numpy(nib.astype(np.int32))
+
+
+def test_gptq_unsupported_bits(ops):
+    a = torch.zeros(1, 128, dtype=torch.float16, device=DEV)
+    qw = torch.zeros(128 // 4, 64, dtype=torch.int32, device=DEV)
+    z = torch.zeros(1, 16, dtype=torch.int32, device=DEV)
+    s = torch.zeros(1, 64, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="only 4-bit"):
+        ops.gptq_gemm(a, qw, z, s, torch.empty(0, device=DEV), True, 8)
