@@ -1,0 +1,82 @@
+"""AWQ — mirror of vllm/model_executor/layers/quantization/awq.py (config :13-73, method :76-176)."""
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch.nn.parameter import Parameter
+
+from neuralmagic_vllm_amd import _custom_ops as ops
+from neuralmagic_vllm_amd.layers.quantization.base_config import LinearMethodBase, QuantizationConfig, set_weight_attrs
+
+
+class AWQConfig(QuantizationConfig):
+
+    def __init__(self, weight_bits: int, group_size: int, zero_point: bool) -> None:
+        self.weight_bits, self.group_size, self.zero_point = weight_bits, group_size, zero_point
+        if self.weight_bits != 4:
+            raise ValueError("Currently, only 4-bit weight quantization is supported for "
+                             f"AWQ, but got {self.weight_bits} bits.")
+        self.pack_factor = 32 // self.weight_bits
+
+    def __repr__(self) -> str:
+        return f"AWQConfig(weight_bits={self.weight_bits}, group_size={self.group_size}, zero_point={self.zero_point})"
+
+    def get_name(self) -> str:
+        return "awq"
+
+    def get_supported_act_dtypes(self) -> List[torch.dtype]:
+        return [torch.half]
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        return ["quant_config.json", "quantize_config.json"]
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "AWQConfig":
+        return cls(cls.get_from_keys(config, ["w_bit", "bits"]), cls.get_from_keys(config, ["q_group_size", "group_size"]),
+                   cls.get_from_keys(config, ["zero_point"]))
+
+    def get_quant_method(self, layer: torch.nn.Module) -> Optional["AWQLinearMethod"]:
+        return AWQLinearMethod(self)
+
+    def get_scaled_act_names(self) -> List[str]:
+        return ["gelu", "gelu_fast", "gelu_new", "gelu_pytorch_tanh"]
+
+
+class AWQLinearMethod(LinearMethodBase):
+
+    def __init__(self, quant_config: AWQConfig):
+        self.quant_config = quant_config
+
+    def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int, output_partition_sizes: List[int],
+                       input_size: int, output_size: int, params_dtype: torch.dtype, **extra_weight_attrs):
+        cfg = self.quant_config
+        if input_size_per_partition % cfg.group_size != 0:
+            raise ValueError("The input size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+        out_pp = sum(output_partition_sizes)
+        if out_pp % cfg.pack_factor != 0:
+            raise ValueError("The output size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+        packed = {"input_dim": 0, "output_dim": 1, "packed_dim": 1, "pack_factor": cfg.pack_factor}
+        qweight = Parameter(torch.empty(input_size_per_partition, out_pp // cfg.pack_factor, dtype=torch.int32), requires_grad=False)
+        set_weight_attrs(qweight, dict(packed))
+        qzeros = Parameter(torch.empty(input_size_per_partition // cfg.group_size, out_pp // cfg.pack_factor, dtype=torch.int32),
+                           requires_grad=False)
+        set_weight_attrs(qzeros, dict(packed))
+        scales = Parameter(torch.empty(input_size_per_partition // cfg.group_size, out_pp, dtype=params_dtype), requires_grad=False)
+        set_weight_attrs(scales, {"input_dim": 0, "output_dim": 1})
+        for name, prm in (("qweight", qweight), ("qzeros", qzeros), ("scales", scales)):
+            layer.register_parameter(name, prm)
+            set_weight_attrs(prm, extra_weight_attrs)
+
+    def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        pack_factor = self.quant_config.pack_factor
+        out_shape = x.shape[:-1] + (layer.qweight.shape[-1] * pack_factor, )
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        if x.shape[:-1].numel() >= 256:  # awq.py:166-170: large batches dequantise once and use a dense GEMM
+            out = torch.matmul(reshaped_x, ops.awq_dequantize(layer.qweight, layer.scales, layer.qzeros, 0, 0, 0))
+        else:
+            out = ops.awq_gemm(reshaped_x, layer.qweight, layer.scales, layer.qzeros, pack_factor)
+        if bias is not None:
+            out.add_(bias)
+        return out.reshape(out_shape)
