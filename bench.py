@@ -253,6 +253,28 @@ def cpu_baseline(cfg, batch, ctx):
                 f"sample took {t_total:.1f} s")
 
 
+def pmc_traffic(kernels, args):
+    """HBM bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command;
+    tools/profile_round.sh) from the newest committed profiles/rNN_kernel_summary.json. PMC counters cannot be read
+    from inside a normal run, so the figure is only attached when the profiled workload is the one being run."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_kernel_summary.json")))
+    if not files:
+        return None, None
+    try:
+        prof = json.load(open(files[-1]))
+        meta = prof.get("_workload", {"batch": 64, "ctx": 1024})
+        if meta.get("batch") != args.batch or meta.get("ctx") != args.ctx:
+            return None, None
+        tot = 0.0
+        for k in kernels:
+            tot += prof[k]["fetch_bytes_per_launch_corrected"] + prof[k]["write_bytes_per_launch"]
+        return int(tot), os.path.relpath(files[-1], here)
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -311,19 +333,33 @@ def main():
     if rank == 0:
         kb = kernel_breakdown(model)
         per_step = {k: v["ms"] * v["launches"] for k, v in kb.items()}
-        dom = max(per_step, key=per_step.get)
-        d = kb[dom]
-        is_gemm = dom.startswith("int4_gemm")
+        # kernel classes: the four int4 GEMM launches of a layer are one kernel (marlin_gemm_kernel [+ its split-K reduce]);
+        # per-launch figures are the mean over the four shapes, which is what rocprofv3's per-kernel average reports too.
+        gem = [v for k, v in kb.items() if k.startswith("int4_gemm")]
+        att = [v for k, v in kb.items() if k.startswith("paged_attention")][0]
+        gem_ms = sum(v["ms"] for v in gem)
+        classes = {
+            "marlin_gemm_kernel": dict(ms=gem_ms / len(gem), bytes=sum(v["bytes"] for v in gem) / len(gem),
+                                       flops=sum(v["flops"] for v in gem) / len(gem), step_ms=gem_ms * gem[0]["launches"],
+                                       prof=("marlin_gemm_kernel", "splitk_reduce_kernel")),
+            "paged_attention_kernel": dict(ms=att["ms"], bytes=att["bytes"], flops=att["flops"],
+                                           step_ms=att["ms"] * att["launches"], prof=("paged_attention_kernel", )),
+        }
+        dom = max(classes, key=lambda k: classes[k]["step_ms"])
+        d = classes[dom]
+        d["gbs"] = d["bytes"] / d["ms"] / 1e6
+        d["tflops"] = d["flops"] / d["ms"] / 1e9
         # HBM-bound below the ridge (4*M flop/B vs ~312 flop/B machine balance)
-        hbm_bound = (not is_gemm) or (d["flops"] / d["bytes"] < MFMA_F16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9))
+        hbm_bound = d["flops"] / d["bytes"] < MFMA_F16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+        traffic, traffic_src = pmc_traffic(d["prof"], args)
         if hbm_bound:
             roof = dict(bound="hbm", kernel=dom, achieved=round(d["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(d["gbs"] / HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(d["ms"] * 1e3, 2),
-                        algorithmic_bytes_per_launch=int(d["bytes"]))
+                        frac=round(d["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
+                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_bytes_per_launch=int(d["bytes"]))
         else:
             roof = dict(bound="mfma", kernel=dom, achieved=round(d["tflops"], 1), peak=MFMA_F16_PEAK_TF, unit="TFLOP/s",
-                        frac=round(d["tflops"] / MFMA_F16_PEAK_TF, 4), traffic=None, avg_launch_us=round(d["ms"] * 1e3, 2),
-                        algorithmic_flops_per_launch=float(d["flops"]))
+                        frac=round(d["tflops"] / MFMA_F16_PEAK_TF, 4), traffic=traffic, traffic_source=traffic_src,
+                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_flops_per_launch=float(d["flops"]))
         result = {
             "metric": "decode tokens/sec, Llama-3-8B GPTQ-int4 (Marlin-format) TP=1",
             "value": round(value, 1),
