@@ -132,6 +132,16 @@ int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scal
                     int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int size_m, int size_n,
                     int size_k, int num_groups, nmx_stream_t stream);
 
+/* gptq_marlin_24_gemm (csrc/quantization/marlin/sparse/marlin_24_cuda_kernel.cu:1017-1125): C = A * W24, W 2:4-sparse
+ * along K. b_q_weight [size_k/2/16, size_n*16/pack_factor] int32 kept values (Marlin-24 permutation,
+ * marlin_24_perms.py:16-50); b_meta [size_k/32, size_n*2] int16 2-bit positions in the CUTLASS reordered layout
+ * (format_24.py:21-50,171-177); b_scales [num_groups, size_n] with num_groups == 1 or size_k/128; fp16 only
+ * (gptq_marlin_24.py:145-147); size_n % 128 == 0; workspace_numel >= (size_n/128)*64. Runs on the hardware sparse
+ * MFMA (v_smfmac_f32_16x16x32_f16): the compressed operand is never expanded. */
+int nmx_gptq_marlin_24_gemm(const void* a, const int32_t* b_q_weight, const void* b_meta, const void* b_scales,
+                            void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int num_bits,
+                            int size_m, int size_n, int size_k, int num_groups, int dtype, nmx_stream_t stream);
+
 /* fp8_marlin_gemm (csrc/quantization/fp8/fp8_marlin.cu:1212-1308): W8A16, weight bytes are e4m3fn, channel-wise
  * scales [1, size_n] (Marlin single-permuted). */
 int nmx_fp8_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,

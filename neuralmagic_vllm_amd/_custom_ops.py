@@ -470,6 +470,50 @@ def marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tenso
     return c
 
 
+def gptq_marlin_24_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_meta: torch.Tensor, b_scales: torch.Tensor,
+                        workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    # checks mirror csrc/quantization/marlin/sparse/marlin_24_cuda_kernel.cu:1024-1082
+    if num_bits not in (4, 8):
+        raise RuntimeError(f"num_bits must be 4 or 8. Got = {num_bits}")
+    pack_factor = 32 // num_bits
+    if a.size(0) != size_m:
+        raise RuntimeError(f"Shape mismatch: a.size(0) = {a.size(0)}, size_m = {size_m}")
+    if a.size(1) != size_k:
+        raise RuntimeError(f"Shape mismatch: a.size(1) = {a.size(1)}, size_k = {size_k}")
+    if size_k % 16 != 0:
+        raise RuntimeError(f"size_k = {size_k} is not divisible by tile_size = 16")
+    if (size_k // 16 // 2) != b_q_weight.size(0):
+        raise RuntimeError(f"Shape mismatch: b_q_weight.size(0) = {b_q_weight.size(0)}, size_k = {size_k}, "
+                           "tile_size = 16")
+    if b_scales.size(1) != size_n:
+        raise RuntimeError(f"b_scales.size(1) = {b_scales.size(1)}, size_n = {size_n}")
+    if b_q_weight.size(1) % 16 != 0:
+        raise RuntimeError(f"b_q_weight.size(1) = {b_q_weight.size(1)} is not divisible by tile_size = 16")
+    actual_size_n = (b_q_weight.size(1) // 16) * pack_factor
+    if size_n != actual_size_n:
+        raise RuntimeError(f"size_n = {size_n}, actual_size_n = {actual_size_n}")
+    if b_meta.size(0) != size_k // 8 // 2 // 2:
+        raise RuntimeError(f"b_meta.size(0) = {b_meta.size(0)} is not size_k / 8 / 2 / 2 = {size_k // 8 // 2 // 2}")
+    if b_meta.size(1) != size_n * 2:
+        raise RuntimeError(f"b_meta.size(1) = {b_meta.size(1)} is not size_n * 2 = {size_n * 2}")
+    for name, t in (("A", a), ("b_q_weight", b_q_weight), ("b_meta", b_meta), ("b_scales", b_scales)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} is not on GPU")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} is not contiguous")
+    if a.dtype != torch.float16:
+        raise RuntimeError("gptq_marlin_24_gemm only supports float16")
+    if b_meta.dtype != torch.int16:
+        raise RuntimeError("b_meta must be int16")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    _lib.check(_lib.lib().nmx_gptq_marlin_24_gemm(_p(a), _p(b_q_weight), _p(b_meta), _p(b_scales), _p(c),
+                                                  c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()),
+                                                  c_int(num_bits), c_int(size_m), c_int(size_n), c_int(size_k),
+                                                  c_int(b_scales.size(0)), c_int(_dt(a)), _stream(a)))
+    return c
+
+
 def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor, workspace: torch.Tensor,
                     num_bits: int, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
     # checks mirror csrc/quantization/fp8/fp8_marlin.cu:1212-1280

@@ -1,832 +1,8 @@
-// Marlin-format W4A16 / W8A16 / fp8-W8A16 GEMMs and the GPTQ->Marlin repack for gfx950.
-//
-// Replaces csrc/quantization/gptq_marlin/{gptq_marlin.cu, gptq_marlin_repack.cu},
-// csrc/quantization/marlin/dense/marlin_cuda_kernel.cu and csrc/quantization/fp8/fp8_marlin.cu of the reference.
-//
-// The op contract hands over weights in the *Marlin layout* (built for NVIDIA mma.m16n8k16 fragments). It turns out
-// to be directly consumable by MFMA 16x16x32 with zero re-layout:
-//   * one lane's 16-byte load of a Marlin row (k-tile kt, 64-column group, chunk i = 4 c + m) holds, for the 8
-//     columns {c, c+8} + 16 j (j = 0..3), the 4 k-rows {2m, 2m+1, 2m+8, 2m+9} of the 16-row k-tile;
-//   * taking k-tiles 2 ks and 2 ks + 1 gives the lane 8 k-values for each of 8 columns = eight MFMA operand
-//     fragments, provided the activation operand uses the same k order inside each 32-k step
-//     (slot (g, jj) <-> k = 16 (jj >> 2) + 2 g + {0, 1, 8, 9}[jj & 3]);
-//   * a wave's 64 lanes (c = lane & 7, m = lane >> 4, column-group = (lane >> 3) & 1) cover 1 KiB of contiguous
-//     HBM per load instruction: fully coalesced, every fetched bit is used exactly once.
-// So the weight stream goes HBM -> VGPR -> dequant (2 VALU per packed pair) -> MFMA with no LDS round trip and no
-// repack pass. Activations (tiny, L2-resident) are staged per wave into LDS in fragment order.
-//
-// This file holds the "skinny" kernel (M <= 64 rows per pass, HBM-bound regime of decode). Rows are processed in
-// blocks of 16 * MT; K is split over the 4 waves of a workgroup (LDS tree reduce) and over gridDim.y workgroups
-// (fp32 partial slabs + a small reduce kernel).
-//
-// Algorithmic bytes per call: K*N*bits/8 (weights) + groups*N*2 (scales) + 2*M*K + 2*M*N.
-#include <stdlib.h>
-#include <type_traits>
-
-#include "nmx_common.h"
+// Entry points of the dense Marlin-format GEMMs (gptq_marlin_gemm, marlin_gemm, fp8_marlin_gemm) and the GPTQ->Marlin
+// repack; the kernel itself lives in marlin_kernel.h (shared with the 2:4-sparse variant in marlin24_gemm.hip).
+#include "marlin_kernel.h"
 
 namespace {
-
-constexpr int kSubSteps = 4;  // 32-k steps per activation staging sub-chunk (128 k)
-
-enum WeightKind { W_INT4 = 0, W_INT8 = 1, W_FP8 = 2 };
-
-template <typename scalar_t>
-__device__ __forceinline__ f32x4 mfma_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
-  if constexpr (__is_same(scalar_t, f16)) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  } else {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-}
-
-// (q & mask) | magic in ONE VALU op. hipcc splits the C expression into v_and + v_or because a VOP3 on gfx950 cannot
-// carry two literals; with the mask in an SGPR and the magic number in a VGPR it is a single v_and_or_b32.
-__device__ __forceinline__ uint32_t and_or(uint32_t q, uint32_t mask, uint32_t magic) {
-  uint32_t r;
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(mask), "v"(magic));
-  return r;
-}
-
-// raw buffer descriptor (wave-uniform): base, num_records = bytes, untyped dword access. Loads past `bytes` return 0.
-__device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
-  const uint64_t a = (uint64_t)p;
-  i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-// Buffer loads as inline asm: destination updated in place ("+v"), per-lane byte offset in a VGPR, the wave-uniform
-// running offset in an SGPR -> no per-load VALU address arithmetic. The leading s_nop covers the SALU-write ->
-// VMEM-read hazard on the soffset / descriptor SGPRs, which hipcc does not pad inside an asm statement.
-__device__ __forceinline__ void buf_load_x2(u32x2& dst, int voff, i32x4 rsrc, int soff) {
-  soff = __builtin_amdgcn_readfirstlane(soff);  // wave-uniform by construction (depends on the wave id only)
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void buf_load_x4(u32x4& dst, int voff, i32x4 rsrc, int soff) {
-  soff = __builtin_amdgcn_readfirstlane(soff);
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-
-__device__ __forceinline__ uint32_t h2_bits(f16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ f16x2 bits_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
-
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  union { bf16 h[2]; uint32_t u; } r;
-  r.h[0] = (bf16)lo;
-  r.h[1] = (bf16)hi;
-  return r.u;
-}
-
-// ---- dequantisation of one packed dword into two operand dwords --------------------------------------------
-// int4, fp16: q holds (after the optional >> 8 for the "+8 column" half) nibbles n0 n1 . . n4 n5 . .
-//   (n0, n4) = k-rows (2m, 2m+1), (n1, n5) = k-rows (2m+8, 2m+9).
-// Exact integer -> fp16 conversion with the 0x6400 exponent trick (same constants the reference relies on,
-// gptq_marlin.cu:162-181): (q & 0x000f000f) | 0x64006400 = 1024 + v ; (q & 0x00f000f0) | 0x64006400 = 1024 + 16 v.
-template <typename scalar_t, int KIND>
-struct Dequant;
-
-template <>
-struct Dequant<f16, W_INT4> {
-  // s2 = (s, s) packed fp16 scale for this column, or 1.0
-  static __device__ __forceinline__ void run(uint32_t q, uint32_t s2, bool scaled, uint32_t& w01, uint32_t& w23) {
-    const f16x2 a = bits_h2(and_or(q, 0x000f000fu, 0x64006400u)) - bits_h2(0x64086408u);                       // v - 8
-    const f16x2 b = bits_h2(and_or(q, 0x00f000f0u, 0x64006400u)) * bits_h2(0x2c002c00u) + bits_h2(0xd480d480u);  // /16 - 72
-    if (scaled) {
-      w01 = h2_bits(a * bits_h2(s2));
-      w23 = h2_bits(b * bits_h2(s2));
-    } else {
-      w01 = h2_bits(a);
-      w23 = h2_bits(b);
-    }
-  }
-};
-
-template <>
-struct Dequant<f16, W_INT8> {
-  // bytes b0 b1 b2 b3 = v0 v2 v1 v3 (k-rows 2m, 2m+8, 2m+1, 2m+9); zero point 128
-  static __device__ __forceinline__ void run(uint32_t q, uint32_t s2, bool scaled, uint32_t& w01, uint32_t& w23) {
-    const f16x2 a = bits_h2(and_or(q, 0x00ff00ffu, 0x64006400u)) - bits_h2(0x64806480u);         // 1024 + b - 1152
-    const f16x2 b = bits_h2(and_or(q >> 8, 0x00ff00ffu, 0x64006400u)) - bits_h2(0x64806480u);
-    if (scaled) {
-      w01 = h2_bits(a * bits_h2(s2));
-      w23 = h2_bits(b * bits_h2(s2));
-    } else {
-      w01 = h2_bits(a);
-      w23 = h2_bits(b);
-    }
-  }
-};
-
-template <>
-struct Dequant<f16, W_FP8> {
-  // e4m3fn byte -> fp16: move sign, shift exponent/mantissa into place, fix the bias with * 2^8
-  // (same construction as fp8/fp8_marlin.cu:132-196)
-  static __device__ __forceinline__ uint32_t cvt(uint32_t t) {  // t = 0x00XX00YY
-    const uint32_t r = ((t << 8) & 0x80008000u) | ((t << 7) & 0x3f803f80u);
-    return h2_bits(bits_h2(r) * bits_h2(0x5c005c00u));  // * 256
-  }
-  static __device__ __forceinline__ void run(uint32_t q, uint32_t s2, bool scaled, uint32_t& w01, uint32_t& w23) {
-    w01 = cvt(q & 0x00ff00ffu);
-    w23 = cvt((q >> 8) & 0x00ff00ffu);
-    if (scaled) {
-      w01 = h2_bits(bits_h2(w01) * bits_h2(s2));
-      w23 = h2_bits(bits_h2(w23) * bits_h2(s2));
-    }
-  }
-};
-
-// bf16 has no packed arithmetic on gfx950: go through fp32 (exact integer, one rounding at the end).
-// s2 carries the fp32 scale bits for bf16.
-template <>
-struct Dequant<bf16, W_INT4> {
-  static __device__ __forceinline__ void run(uint32_t q, uint32_t sbits, bool scaled, uint32_t& w01, uint32_t& w23) {
-    const float s = scaled ? __builtin_bit_cast(float, sbits) : 1.0f;
-    const float v0 = (float)(int)(q & 0xf) - 8.f, v1 = (float)(int)((q >> 16) & 0xf) - 8.f;
-    const float v2 = (float)(int)((q >> 4) & 0xf) - 8.f, v3 = (float)(int)((q >> 20) & 0xf) - 8.f;
-    w01 = pack_bf16(v0 * s, v1 * s);
-    w23 = pack_bf16(v2 * s, v3 * s);
-  }
-};
-template <>
-struct Dequant<bf16, W_INT8> {
-  static __device__ __forceinline__ void run(uint32_t q, uint32_t sbits, bool scaled, uint32_t& w01, uint32_t& w23) {
-    const float s = scaled ? __builtin_bit_cast(float, sbits) : 1.0f;
-    const float v0 = (float)(int)(q & 0xff) - 128.f, v1 = (float)(int)((q >> 16) & 0xff) - 128.f;
-    const float v2 = (float)(int)((q >> 8) & 0xff) - 128.f, v3 = (float)(int)((q >> 24) & 0xff) - 128.f;
-    w01 = pack_bf16(v0 * s, v1 * s);
-    w23 = pack_bf16(v2 * s, v3 * s);
-  }
-};
-template <>
-struct Dequant<bf16, W_FP8> {
-  static __device__ __forceinline__ void run(uint32_t q, uint32_t sbits, bool scaled, uint32_t& w01, uint32_t& w23) {
-    const float s = scaled ? __builtin_bit_cast(float, sbits) : 1.0f;
-    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(q, false);  // bytes 0,1 = v0, v2
-    const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(q, true);   // bytes 2,3 = v1, v3
-    w01 = pack_bf16(lo[0] * s, hi[0] * s);
-    w23 = pack_bf16(lo[1] * s, hi[1] * s);
-  }
-};
-
-struct GemmParams {
-  const void* a;           // [M, K]
-  const int32_t* b;        // Marlin-packed weight
-  const void* scales;      // [num_groups, N] Marlin-permuted
-  const int32_t* g_idx;    // [K] or null
-  const int32_t* perm;     // [K] or null
-  void* c;                 // [M, N] scalar_t
-  float* partial;          // [k_splits, M, N] fp32 (k_splits > 1)
-  int M, N, K;
-  int num_groups, group_size;  // group_size = K for channel-wise
-  int k_splits;
-  int slow_act_order;      // act-order with partial K: per-row scale lookup
-};
-
-// ---- the GEMM kernel -------------------------------------------------------------------------------------------
-// Workgroup = 4 waves. Wave w owns 64-column group (w % NG) of the workgroup's 64*NG columns and K-slice (w / NG) of
-// the workgroup's K range (KW = 4 / NG slices, reduced through LDS at the end). Rows: 16*MT per workgroup.
-//   M <= 16 : MT = 1, NG = 1  (each wave streams its own K-slice of one 64-column group; no barriers)
-//   M <= 32 : MT = 2, NG = 2
-//   larger  : MT = 4, NG = 4  (256-column tiles: the activation tile is shared by the 4 waves through LDS so that
-//                              activation re-reads from L2 stay ~1x the weight bytes)
-// Weight stream: lane (g, li), c8 = li & 7, hi = li >> 3 reads from chunk 4 c8 + g of its 64-column group the two
-// words of tiles j = 2 hi, 2 hi + 1 (8 B, int4; 16 B for 8-bit) of BOTH k-tiles of a 32-k step: the 64 lanes cover
-// the group's 512 B (1 KiB) per k-tile exactly once, and every lane owns all four MFMA operand fragments it needs
-// (column c8 + 8 x + 32 hi for x = 0..3) without any cross-lane traffic. A register ring keeps PF k-steps in flight.
-// Activations are double-buffered in LDS in fragment order.
-// grid (ceil(N / (64 NG)), k_splits, ceil(M / (16 MT))), block 256
-// MODE 0: channel-wise scales, MODE 1: group size a multiple of 128 (one scale row per sub-chunk) — both
-// branch-free in the main loop so that hipcc keeps counted vmcnt waits and the weight ring stays in flight;
-// MODE 2: generic (group sizes 32 / 64, act-order column gather, per-row group lookup).
-template <typename scalar_t, int KIND, int MT, int NG, int MODE>
-__global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
-  constexpr bool I4 = (KIND == W_INT4);
-  constexpr bool GENERIC = (MODE == 2);
-  constexpr int SUB = I4 ? 4 : 2;                     // 32-k steps per sub-chunk
-  constexpr int PF = 2 * SUB;                         // k-steps of weights in flight per wave
-  constexpr int NTILE = 4;                            // 16-column MFMA tiles per wave (one 64-column group)
-  constexpr int KW = 4 / NG;                          // K slices per workgroup
-  constexpr int ROWS = 16 * MT;
-  constexpr int WORDS64 = I4 ? 128 : 256;             // int32 per (k-tile, 64-column group)
-  constexpr int ABUF = SUB * 4 * ROWS * 16;           // bytes of one activation buffer
-  constexpr int NPIECE = ROWS * SUB * 4;              // 16-B activation pieces per sub-chunk
-  constexpr int PIECES = (NPIECE + 64 * NG - 1) / (64 * NG);  // per thread
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int g = lane >> 4;
-  const int li = lane & 15;
-  const int c8 = li & 7;
-  const int hi = li >> 3;
-  const int ng = wave % NG;
-  const int kslice = wave / NG;
-
-  const int N = p.N, K = p.K, M = p.M;
-  const int n0 = (blockIdx.x * NG + ng) * 64;   // this wave's 64-column group
-  const bool col_ok = n0 < N;
-  const int m0 = blockIdx.z * ROWS;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_a = smem + (size_t)kslice * 2 * ABUF;  // [2][ABUF] double buffer of this K-slice
-
-  // ---- this K-slice's range of sub-chunks ----
-  const int total_steps = (K + 31) / 32;
-  const int total_sub = (total_steps + SUB - 1) / SUB;
-  const int nworkers = p.k_splits * KW;
-  const int sub_per = (total_sub + nworkers - 1) / nworkers;
-  const int worker = blockIdx.y * KW + kslice;
-  const int sub_begin = min(worker * sub_per, total_sub);
-  const int sub_end = min(sub_begin + sub_per, total_sub);
-  // all K-slices of a workgroup run the same number of iterations (barriers): the longest one
-  const int n_iter = (NG > 1) ? sub_per : (sub_end - sub_begin);
-
-  // ---- weight addressing: lane (g, li) reads chunk 4 c8 + g of its 64-column group from k-tile row 2 ks + hi ----
-  const int ktiles = K / 16;
-  const int64_t row_words = (int64_t)N * 16 / (I4 ? 8 : 4);
-  const int32_t* bw = p.b + (int64_t)((col_ok ? n0 : 0) / 64) * WORDS64 + (4 * c8 + g) * (I4 ? 4 : 8) + (I4 ? 2 : 4) * hi;
-
-  const bool grouped = GENERIC ? (p.num_groups > 1) : (MODE == 1);
-  const bool slow_act = GENERIC && p.slow_act_order;
-  const scalar_t* sc = reinterpret_cast<const scalar_t*>(p.scales);
-  // grouped scales (scale_perm): position 8 c8 + b holds column c8 + 8 b; this lane's tiles are b = 4 hi + x
-  const int64_t scale_off = (int64_t)((col_ok ? n0 : 0) / 64) * 64 + 8 * c8 + 4 * hi;
-
-  uint32_t s2[NTILE];
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t) s2[t] = 0;
-  int cur_group = -1;
-  auto load_group_scales = [&](int grp) {
-    union { u32x2 v; scalar_t e[4]; } raw;
-    raw.v = *reinterpret_cast<const u32x2*>(sc + (int64_t)grp * N + scale_off);
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      const scalar_t sv = raw.e[t];
-      if constexpr (__is_same(scalar_t, f16)) {
-        union { f16 h[2]; uint32_t u; } pk;
-        pk.h[0] = sv;
-        pk.h[1] = sv;
-        s2[t] = pk.u;
-      } else {
-        s2[t] = __builtin_bit_cast(uint32_t, (float)sv);
-      }
-    }
-  };
-
-  f32x4 acc[MT][NTILE];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const scalar_t* A = reinterpret_cast<const scalar_t*>(p.a);
-
-  // one k-step of weights for this lane: its words of k-tile rows 2 ks and 2 ks + 1
-  using bvec_t = typename std::conditional<I4, u32x2, u32x4>::type;
-  struct BStep { bvec_t q[2]; };
-  auto load_b = [&](int kstep, BStep& r) {
-    kstep = min(kstep, total_steps - 1);
-    const int kt0 = 2 * kstep;
-    const int kt1 = min(kt0 + 1, ktiles - 1);  // K % 32 == 16 tail: activations are zero-filled there
-    r.q[0] = *reinterpret_cast<const bvec_t*>(bw + (int64_t)kt0 * row_words);
-    r.q[1] = *reinterpret_cast<const bvec_t*>(bw + (int64_t)kt1 * row_words);
-  };
-  // activation pieces: piece id = it * (64 NG) + ng * 64 + lane -> (row, 16-B chunk of the SUB*32-k slab)
-  struct ARegs { u32x4 v[PIECES]; };
-  auto load_a = [&](int sub, bool valid, ARegs& r) {
-    const int kbase = sub * (SUB * 32);
-#pragma unroll
-    for (int it = 0; it < PIECES; ++it) {
-      const int piece = it * (64 * NG) + ng * 64 + lane;
-      const int row = piece / (SUB * 4);
-      const int cc16 = piece % (SUB * 4);
-      const int k = kbase + cc16 * 8;
-      const int m = m0 + row;
-      const bool ok = valid && piece < NPIECE && m < M && k < K;
-      u32x4 v = {0, 0, 0, 0};
-      if (GENERIC && p.perm != nullptr) {
-        if (ok) {
-          // act-order: A'[m][k] = A[m][perm[k]] (gptq_marlin.cu:345-394)
-          union { scalar_t h[8]; u32x4 u; } gth;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) gth.h[e] = A[(int64_t)m * K + p.perm[k + e]];
-          v = gth.u;
-        }
-      } else {
-        // branch-free: clamp the address, zero by select
-        const int mc = min(m, M - 1), kc = min(k, K - 8);
-        const u32x4 ld = *reinterpret_cast<const u32x4*>(A + (int64_t)mc * K + kc);
-        v = ok ? ld : v;
-      }
-      r.v[it] = v;
-    }
-  };
-  // 16-B chunk (ks = cc16 / 4, cc = cc16 % 4), dword e2 -> fragment (ks, g = e2, row), dword cc
-  auto store_a = [&](const ARegs& r, char* buf) {
-#pragma unroll
-    for (int it = 0; it < PIECES; ++it) {
-      const int piece = it * (64 * NG) + ng * 64 + lane;
-      const int row = piece / (SUB * 4);
-      const int cc16 = piece % (SUB * 4);
-      const int ks = cc16 >> 2, cc = cc16 & 3;
-      if (piece < NPIECE) {
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2)
-          *reinterpret_cast<uint32_t*>(buf + (((ks * 4 + e2) * ROWS + row) * 16) + 4 * cc) = r.v[it][e2];
-      }
-    }
-  };
-  auto sync_slice = [&]() {
-    if constexpr (NG > 1) __syncthreads();
-    else __builtin_amdgcn_wave_barrier();  // wave-private buffer: LDS ops of one wave complete in order
-  };
-
-  // MODE 1 with few row tiles: MFMA on UNSCALED integer-valued weights into per-group accumulators and apply the
-  // group scale once per group in fp32 (16 MT FMAs per 128 k instead of 16 packed multiplies per 32 k). This is
-  // sum_g s_g * (a . (q - 8)) exactly — slightly MORE accurate than the reference's fp16-rounded (q - 8) * s.
-  constexpr bool ACC_SCALE = (MODE == 1) && (MT <= 2);
-  f32x4 gacc[ACC_SCALE ? MT : 1][NTILE];
-  float srow[ACC_SCALE ? NTILE : 1][4];
-
-  // one 32-k step of MFMAs for this wave: weights `cur`, activation fragments from `abuf`.
-  // GA = 0: accumulate (scaled weights) into acc; GA = 1: start a group in gacc; GA = 2: continue in gacc
-  auto compute_step = [&](const BStep& cur, int ksl, int kstep, const char* abuf, auto ga_c) {
-    constexpr int GA = decltype(ga_c)::value;
-    if (GENERIC && grouped && !slow_act) {
-      const int grp = min((kstep * 32) / p.group_size, p.num_groups - 1);
-      if (grp != cur_group) {
-        cur_group = grp;
-        load_group_scales(grp);
-      }
-    }
-    u32x4 af[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      af[mt] = *reinterpret_cast<const u32x4*>(abuf + (((ksl * 4 + g) * ROWS + mt * 16 + li) * 16));
-
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      // tile x = t: column c8 + 8 t + 32 hi. int4: word t >> 1 of the lane's pair, "+8 column" half 8 bits up;
-      // 8-bit: word t of the lane's four
-      uint32_t w0, w1;
-      if constexpr (I4) {
-        w0 = cur.q[0][t >> 1] >> (8 * (t & 1));
-        w1 = cur.q[1][t >> 1] >> (8 * (t & 1));
-      } else {
-        w0 = cur.q[0][t];
-        w1 = cur.q[1][t];
-      }
-      uint32_t d0, d1, d2, d3;
-      u32x4 wf;
-      if (!slow_act) {
-        Dequant<scalar_t, KIND>::run(w0, s2[t], grouped && GA == 0, d0, d1);
-        Dequant<scalar_t, KIND>::run(w1, s2[t], grouped && GA == 0, d2, d3);
-        wf = u32x4{d0, d1, d2, d3};
-      } else {
-        // act-order on a K-shard (is_k_full == false): every k-row carries its own group id
-        // (gptq_marlin.cu:965-980 with g_idx). Dequantise unscaled, then scale element-wise.
-        Dequant<scalar_t, KIND>::run(w0, 0, false, d0, d1);
-        Dequant<scalar_t, KIND>::run(w1, 0, false, d2, d3);
-        union { u32x4 u; scalar_t h[8]; } wv;
-        wv.u = u32x4{d0, d1, d2, d3};
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const int koff[4] = {0, 1, 8, 9};
-          int k = kstep * 32 + 16 * (jj >> 2) + 2 * g + koff[jj & 3];
-          k = min(k, K - 1);
-          const int grp = p.g_idx[k];
-          const float sv = Scalar<scalar_t>::to_f32(sc[(int64_t)grp * N + scale_off + t]);
-          wv.h[jj] = Scalar<scalar_t>::from_f32(Scalar<scalar_t>::to_f32(wv.h[jj]) * sv);
-        }
-        wf = wv.u;
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if constexpr (GA == 0) acc[mt][t] = mfma_16x16x32<scalar_t>(wf, af[mt], acc[mt][t]);
-        else if constexpr (GA == 1) gacc[ACC_SCALE ? mt : 0][t] = mfma_16x16x32<scalar_t>(wf, af[mt], f32x4{0.f, 0.f, 0.f, 0.f});
-        else gacc[ACC_SCALE ? mt : 0][t] = mfma_16x16x32<scalar_t>(wf, af[mt], gacc[ACC_SCALE ? mt : 0][t]);
-      }
-    }
-  };
-  using GA0 = std::integral_constant<int, 0>;
-  using GA1 = std::integral_constant<int, 1>;
-  using GA2 = std::integral_constant<int, 2>;
-
-  if constexpr (GENERIC) {
-    // ---- compiler-scheduled loop (any group size, act-order gather) ----
-    BStep ring[PF];
-    ARegs areg;
-    if (n_iter > 0) {
-#pragma unroll
-      for (int i = 0; i < PF; ++i) load_b(sub_begin * SUB + i, ring[i]);
-      load_a(sub_begin, sub_begin < sub_end, areg);
-      store_a(areg, lds_a);
-    }
-    sync_slice();
-    auto body = [&](auto par_c, int it) {
-      constexpr int PAR = decltype(par_c)::value;
-      const int sub = sub_begin + it;
-      const bool have_next = (sub + 1) < sub_end;
-      load_a(sub + 1, have_next && (it + 1 < n_iter), areg);
-#pragma unroll
-      for (int ksl = 0; ksl < SUB; ++ksl) {
-        const int kstep = sub * SUB + ksl;
-        BStep cur = ring[PAR * SUB + ksl];
-        load_b(kstep + PF, ring[PAR * SUB + ksl]);
-        compute_step(cur, ksl, kstep, lds_a + PAR * ABUF, GA0{});
-      }
-      store_a(areg, lds_a + (PAR ^ 1) * ABUF);
-      sync_slice();
-    };
-    for (int it = 0; it < n_iter; it += 2) {
-      body(std::integral_constant<int, 0>{}, it);
-      if (it + 1 < n_iter) body(std::integral_constant<int, 1>{}, it + 1);
-    }
-  } else {
-    // ---- hand-counted loop: every vector-memory op is an inline-asm load issued in a fixed periodic pattern, so
-    // that every wait is a COUNTED s_waitcnt vmcnt(N) and PF k-steps of weights stay in flight per wave.
-    // Issue order per sub-chunk body:  [batch: PIECES activation loads (+1 scale row) for the NEXT sub-chunk]
-    //                                  then per k-step [wait weights(kstep)] [load weights(kstep + PF)] [compute].
-    // Ops younger than weights(kstep) at its wait: (PF - 1) weight loads + 2 batches  -> vmcnt(PF - 1 + 2 BATCH).
-    // Ops younger than the batch at the end of the body: SUB weight loads           -> vmcnt(SUB).
-    // (vmcnt(N) with N <= #younger ops is always safe; loads past the range are clamped, never skipped, so the
-    // pattern is the same in every iteration, prologue included.)
-    constexpr int NSC = (MODE == 1) ? (ACC_SCALE ? 4 : 1) : 0;  // scale loads per batch
-    constexpr int BATCH = PIECES + NSC;
-    constexpr int WAIT_B = 2 * PF - 2 + 2 * BATCH;   // weight loads are 2 instructions per k-step
-    constexpr int WAIT_BATCH = 2 * SUB;
-    static_assert(WAIT_B < 60, "vmcnt is 6 bits");
-    BStep ring[PF];
-    ARegs areg;
-    u32x2 sraw[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      ring[i].q[0] = bvec_t{};
-      ring[i].q[1] = bvec_t{};
-    }
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) areg.v[i] = u32x4{0, 0, 0, 0};
-
-    // fast modes require K % (32 SUB) == 0, so every k-tile row of an in-range k-step exists; rows past the end of
-    // the matrix (prefetch beyond the slice) are out of the descriptor's range and read as zeros
-    const int row_bytes = (int)(row_words * 4);
-    const i32x4 rs_b = make_rsrc(p.b, (uint32_t)((int64_t)ktiles * row_bytes));
-    const i32x4 rs_a = make_rsrc(p.a, (uint32_t)((int64_t)M * K * sizeof(scalar_t)));
-    const i32x4 rs_s = make_rsrc(p.scales, (uint32_t)((int64_t)p.num_groups * N * sizeof(scalar_t)));
-    const int b_voff = (int)((bw - p.b) * 4);
-    auto issue_b = [&](int kstep, BStep& r) {
-      const int soff = 2 * kstep * row_bytes;  // wave-uniform
-      if constexpr (I4) {
-        buf_load_x2(r.q[0], b_voff, rs_b, soff);
-        buf_load_x2(r.q[1], b_voff, rs_b, soff + row_bytes);
-      } else {
-        buf_load_x4(r.q[0], b_voff, rs_b, soff);
-        buf_load_x4(r.q[1], b_voff, rs_b, soff + row_bytes);
-      }
-    };
-    // per-lane byte offsets of the activation pieces inside a [ROWS x SUB*32] slab at (m0, k = 0)
-    int a_voff[PIECES];
-#pragma unroll
-    for (int it = 0; it < PIECES; ++it) {
-      const int piece = it * (64 * NG) + ng * 64 + lane;
-      const int row = min(piece / (SUB * 4), ROWS - 1);
-      const int cc16 = piece % (SUB * 4);
-      // rows >= M (and the padding pieces of a short tile) get an offset beyond the descriptor's range: the
-      // hardware returns zeros for them without touching memory
-      a_voff[it] = (piece < NPIECE && (m0 + row) < M) ? (int)(((int64_t)(m0 + row) * K + cc16 * 8) * sizeof(scalar_t))
-                                                      : (int)0x7ff00000;
-    }
-    // scale offsets. per-weight scaling: the lane's 4 tile columns c8 + 8 x + 32 hi -> positions 8 c8 + 4 hi + x;
-    // per-group scaling of the accumulators: D row r of tile x is column 32 (g>>1) + 8 x + 4 (g&1) + r ->
-    // position 8 (4 (g&1) + r) + 4 (g>>1) + x: four 8-byte loads (r = 0..3), x contiguous
-    const int s_voff = ACC_SCALE ? (int)((((col_ok ? n0 : 0) / 64) * 64 + 32 * (g & 1) + 4 * (g >> 1)) * sizeof(scalar_t))
-                                 : (int)(scale_off * sizeof(scalar_t));
-    auto issue_batch = [&](int sub) {
-      const int kbase = sub * (SUB * 32);
-      const int soff = kbase * (int)sizeof(scalar_t);  // wave-uniform
-#pragma unroll
-      for (int it = 0; it < PIECES; ++it) buf_load_x4(areg.v[it], a_voff[it], rs_a, soff);
-      if constexpr (MODE == 1) {
-        const int grp = min(kbase / p.group_size, p.num_groups - 1);
-#pragma unroll
-        for (int r = 0; r < NSC; ++r)
-          buf_load_x2(sraw[r], s_voff + 8 * r * (int)sizeof(scalar_t), rs_s, grp * N * (int)sizeof(scalar_t));
-      }
-    };
-    // make the landed batch usable: zero the out-of-range pieces, write the fragments, unpack the scales
-    auto land_batch = [&](int sub, bool valid, char* buf) {
-      const int kbase = sub * (SUB * 32);
-#pragma unroll
-      for (int it = 0; it < PIECES; ++it) {
-        const int piece = it * (64 * NG) + ng * 64 + lane;
-        const int row = piece / (SUB * 4);
-        const int cc16 = piece % (SUB * 4);
-        const bool ok = valid && piece < NPIECE && (m0 + row) < M && (kbase + cc16 * 8) < K;
-        areg.v[it] = ok ? areg.v[it] : u32x4{0, 0, 0, 0};
-      }
-      store_a(areg, buf);
-      if constexpr (ACC_SCALE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          union { u32x2 v; scalar_t e[4]; } raw;
-          raw.v = sraw[r];
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t) srow[t][r] = Scalar<scalar_t>::to_f32(raw.e[t]);
-        }
-      } else if constexpr (MODE == 1) {
-        union { u32x2 v; scalar_t e[4]; } raw;
-        raw.v = sraw[0];
-#pragma unroll
-        for (int t = 0; t < NTILE; ++t) {
-          const scalar_t sv = raw.e[t];
-          if constexpr (__is_same(scalar_t, f16)) {
-            union { f16 h[2]; uint32_t u; } pk;
-            pk.h[0] = sv;
-            pk.h[1] = sv;
-            s2[t] = pk.u;
-          } else {
-            s2[t] = __builtin_bit_cast(uint32_t, (float)sv);
-          }
-        }
-      }
-    };
-    auto wait_batch = [&]() {
-      // binds every batch destination so that no use can be scheduled above the wait
-      if constexpr (PIECES == 1)
-        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(areg.v[0]), "+v"(sraw[0]), "+v"(sraw[1]), "+v"(sraw[2]), "+v"(sraw[3])
-                     : "n"(WAIT_BATCH) : "memory");
-      else if constexpr (PIECES == 2)
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(areg.v[0]), "+v"(areg.v[1]), "+v"(sraw[0]), "+v"(sraw[1]), "+v"(sraw[2]), "+v"(sraw[3])
-                     : "n"(WAIT_BATCH) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(areg.v[0]), "+v"(areg.v[1]), "+v"(areg.v[2]), "+v"(areg.v[3]), "+v"(sraw[0]),
-                     "+v"(sraw[1]), "+v"(sraw[2]), "+v"(sraw[3]) : "n"(WAIT_BATCH) : "memory");
-    };
-    static_assert(PIECES == 1 || PIECES == 2 || PIECES == 4, "unsupported activation piece count");
-    auto wait_b = [&](BStep& r) {
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.q[0]), "+v"(r.q[1]) : "n"(WAIT_B) : "memory");
-    };
-
-    if (n_iter > 0) {
-      // prologue in the steady-state pattern: [batch] [SUB weight loads] [batch] [SUB weight loads]
-      issue_batch(sub_begin);
-#pragma unroll
-      for (int i = 0; i < SUB; ++i) issue_b(sub_begin * SUB + i, ring[i]);
-      issue_batch(sub_begin);
-#pragma unroll
-      for (int i = SUB; i < PF; ++i) issue_b(sub_begin * SUB + i, ring[i]);
-      wait_batch();
-      land_batch(sub_begin, sub_begin < sub_end, lds_a);
-    }
-    sync_slice();
-
-    auto body = [&](auto par_c, int it) {
-      constexpr int PAR = decltype(par_c)::value;
-      const int sub = sub_begin + it;
-      const bool have_next = ((sub + 1) < sub_end) && (it + 1 < n_iter);
-      issue_batch(sub + 1);
-#pragma unroll
-      for (int ksl = 0; ksl < SUB; ++ksl) {
-        const int kstep = sub * SUB + ksl;
-        wait_b(ring[PAR * SUB + ksl]);
-        if constexpr (!ACC_SCALE) compute_step(ring[PAR * SUB + ksl], ksl, kstep, lds_a + PAR * ABUF, GA0{});
-        else if (ksl == 0) compute_step(ring[PAR * SUB + ksl], ksl, kstep, lds_a + PAR * ABUF, GA1{});
-        else compute_step(ring[PAR * SUB + ksl], ksl, kstep, lds_a + PAR * ABUF, GA2{});
-        issue_b(kstep + PF, ring[PAR * SUB + ksl]);
-      }
-      if constexpr (ACC_SCALE) {
-        // one group (sub-chunk) done: acc += scale[column] * group accumulator
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][t][r] += srow[t][r] * gacc[mt][t][r];
-      }
-      wait_batch();
-      land_batch(sub + 1, have_next, lds_a + (PAR ^ 1) * ABUF);
-      sync_slice();
-    };
-    for (int it = 0; it < n_iter; it += 2) {
-      body(std::integral_constant<int, 0>{}, it);
-      if (it + 1 < n_iter) body(std::integral_constant<int, 1>{}, it + 1);
-    }
-    // drain: no asm load may still be in flight when its destination registers are reused below
-    if (n_iter > 0) {
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[i].q[0]), "+v"(ring[i].q[1])::"memory");
-      }
-    }
-  }
-
-  // ---- channel-wise scales are applied to the fp32 accumulators (rows of D = column slots 4 g + r) ----
-  if (!grouped && !slow_act) {
-    // scale_perm_single (marlin_perms.py:44-47): within a 32-column chunk position 8 (c/2) + (c%2) + 2 b' holds
-    // column c + 8 b'. D row 4 g + r of tile x is column 32 (g >> 1) + 8 x + 4 (g & 1) + r of the 64 group.
-    const int64_t base64 = (int64_t)((col_ok ? n0 : 0) / 64) * 64;
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = 32 * (g >> 1) + 8 * t + 4 * (g & 1) + r;
-        const int cc = col & 7, b = col >> 3;
-        const int pos = 32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3);
-        const float sv = Scalar<scalar_t>::to_f32(sc[base64 + pos]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][t][r] *= sv;
-      }
-    }
-  }
-
-  // ---- reduce the KW K-slices (tree through LDS); slice 0 writes ----
-  constexpr int ACC_FLOATS = MT * NTILE * 64 * 4;
-  float* red = reinterpret_cast<float*>(smem);
-  if constexpr (KW > 1) {
-#pragma unroll
-    for (int stride = KW / 2; stride >= 1; stride >>= 1) {
-      __syncthreads();
-      if (kslice >= stride && kslice < 2 * stride) {
-        float* dst = red + ((kslice - stride) * NG + ng) * ACC_FLOATS;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t) *reinterpret_cast<f32x4*>(dst + ((mt * NTILE + t) * 64 + lane) * 4) = acc[mt][t];
-      }
-      __syncthreads();
-      if (kslice < stride) {
-        const float* src = red + (kslice * NG + ng) * ACC_FLOATS;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t)
-            acc[mt][t] += *reinterpret_cast<const f32x4*>(src + ((mt * NTILE + t) * 64 + lane) * 4);
-      }
-    }
-  }
-  if (kslice != 0 || !col_ok) return;
-
-  // lane (g, li): D rows = 4 consecutive output columns 32 (g >> 1) + 8 t + 4 (g & 1) + r, D col = activation row li
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t) {
-    const int n = n0 + 32 * (g >> 1) + 8 * t + 4 * (g & 1);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = m0 + mt * 16 + li;
-      if (m >= M) continue;
-      if (p.k_splits == 1) {
-        union { scalar_t h[4]; u32x2 u; } r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
-        *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = r.u;
-      } else {
-        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * M + m) * N + n) = acc[mt][t];
-      }
-    }
-  }
-}
-
-// out[m][n] = cast(sum_s partial[s][m][n]); 4 columns per thread
-template <typename scalar_t>
-__global__ void splitk_reduce_kernel(scalar_t* __restrict__ c, const float* __restrict__ partial, int64_t mn4, int splits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= mn4) return;
-  f32x4 acc = *reinterpret_cast<const f32x4*>(partial + i * 4);
-  for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * mn4 + i) * 4);
-  union { scalar_t h[4]; u32x2 u; } r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
-  *reinterpret_cast<u32x2*>(c + i * 4) = r.u;
-}
-
-// ---- GPTQ -> Marlin repack (gptq_marlin_repack.cu:32-260; element map SURVEY.md appendix A.2) ----------------
-// one thread per output int32
-template <int BITS>
-__global__ void marlin_repack_kernel(const uint32_t* __restrict__ in, const int32_t* __restrict__ perm,
-                                     uint32_t* __restrict__ out, int size_k, int size_n) {
-  constexpr int PF = 32 / BITS;
-  constexpr int WORDS64 = 1024 / PF;  // words per (k-tile, 64-column group)
-  const int64_t row_words = (int64_t)size_n * 16 / PF;
-  const int64_t total = (int64_t)(size_k / 16) * row_words;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int kt = idx / row_words;
-  const int w = idx % row_words;
-  const int ng = w / WORDS64;
-  const int wi = w % WORDS64;
-  int i, j, part;
-  if constexpr (BITS == 4) { i = wi >> 2; j = wi & 3; part = 0; }
-  else { i = wi >> 3; j = (wi >> 1) & 3; part = wi & 1; }
-  const int col = i >> 2;
-  const int row0 = 2 * (i & 3);
-  const int rows[4] = {row0, row0 + 1, row0 + 8, row0 + 9};
-  auto fetch = [&](int e) -> uint32_t {  // element e of v[0..7]
-    int k = kt * 16 + rows[e & 3];
-    const int n = ng * 64 + 16 * j + col + 8 * (e >> 2);
-    if (perm != nullptr) k = perm[k];
-    const uint32_t word = in[(int64_t)(k / PF) * size_n + n];
-    return (word >> (BITS * (k % PF))) & ((1u << BITS) - 1);
-  };
-  uint32_t r = 0;
-  if constexpr (BITS == 4) {
-    const int il[8] = {0, 2, 4, 6, 1, 3, 5, 7};
-#pragma unroll
-    for (int pz = 0; pz < 8; ++pz) r |= fetch(il[pz]) << (4 * pz);
-  } else {
-    const int il[4] = {0, 2, 1, 3};
-#pragma unroll
-    for (int pz = 0; pz < 4; ++pz) r |= fetch(4 * part + il[pz]) << (8 * pz);
-  }
-  out[idx] = r;
-}
-
-struct GemmCfg { int mt, ng, splits; };
-
-// Tile shape by M; K splits so that the grid fills the chip (~2 workgroups per CU) while the fp32 partial traffic
-// (splits * M * N * 8 bytes written + read) stays below about half of the weight bytes.
-GemmCfg pick_cfg(int M, int N, int K) {
-  GemmCfg c;
-  if (M <= 16) { c.mt = 1; c.ng = 1; }
-  else if (M <= 32) { c.mt = 2; c.ng = 2; }
-  else { c.mt = 4; c.ng = 4; }
-  if (const char* e = getenv("NMX_GEMM_CFG")) {  // tuning override: "mt,ng,splits"
-    int a = 0, b = 0, s = 0;
-    if (sscanf(e, "%d,%d,%d", &a, &b, &s) == 3 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && s >= 1 && !(a == 4 && b != 4) && !(a == 2 && b == 1)) {
-      c.mt = a; c.ng = b; c.splits = s;
-      return c;
-    }
-  }
-  // measured on MI355X (tools/gemm_sweep.py): ~384 workgroups of the narrow tiles / ~256 of the wide ones fill the
-  // chip; more K splits only add partial-sum traffic and a longer reduce
-  const int n_tiles = ceil_div(N, 64 * c.ng);
-  const int m_blocks = ceil_div(M, 16 * c.mt);
-  const int kw = 4 / c.ng;
-  const int total_sub = ceil_div(ceil_div(K, 32), 4);
-  const int target = (c.ng == 4) ? 256 : 384;
-  int splits = (n_tiles * m_blocks >= target) ? 1 : ceil_div(target, n_tiles * m_blocks);
-  const int cap_work = std::max(1, total_sub / (2 * kw));  // >= 2 sub-chunks per K-slice
-  splits = std::max(1, std::min(splits, std::min(cap_work, 16)));
-  c.splits = splits;
-  return c;
-}
-
-template <typename scalar_t, int KIND, int MT, int NG, int MODE>
-int launch_cfg(const GemmParams& p, hipStream_t stream) {
-  constexpr int SUB = (KIND == W_INT4) ? 4 : 2;
-  constexpr int KW = 4 / NG;
-  const size_t stage = (size_t)KW * 2 * SUB * 4 * (16 * MT) * 16;
-  const size_t red = (KW > 1) ? (size_t)(KW / 2) * NG * MT * 4 * 64 * 4 * sizeof(float) : 0;
-  const size_t smem = std::max(stage, red);
-  dim3 grid(ceil_div(p.N, 64 * NG), p.k_splits, ceil_div(p.M, 16 * MT));
-  auto kern = marlin_gemm_kernel<scalar_t, KIND, MT, NG, MODE>;
-  if (smem > 64 * 1024)
-    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  kern<<<grid, 256, smem, stream>>>(p);
-  NMX_LAUNCH_CHECK();
-  return NMX_OK;
-}
-
-template <typename scalar_t, int KIND, int MODE>
-int launch_mode(const GemmParams& p, const GemmCfg& cfg, hipStream_t stream) {
-  if (cfg.mt == 1 && cfg.ng == 1) return launch_cfg<scalar_t, KIND, 1, 1, MODE>(p, stream);
-  if (cfg.mt == 1 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 1, 2, MODE>(p, stream);
-  if (cfg.mt == 1) return launch_cfg<scalar_t, KIND, 1, 4, MODE>(p, stream);
-  if (cfg.mt == 2 && cfg.ng == 4) return launch_cfg<scalar_t, KIND, 2, 4, MODE>(p, stream);
-  if (cfg.mt == 2) return launch_cfg<scalar_t, KIND, 2, 2, MODE>(p, stream);
-  return launch_cfg<scalar_t, KIND, 4, 4, MODE>(p, stream);
-}
-
-template <typename scalar_t, int KIND>
-int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
-  GemmCfg cfg = pick_cfg(p.M, p.N, p.K);
-  p.k_splits = cfg.splits;
-  if (p.k_splits > 1) {
-    const int64_t need = (int64_t)p.k_splits * p.M * p.N * sizeof(float);
-    if (scratch == nullptr || scratch_bytes < need) {
-      // degrade to the number of splits that fits (never allocate here: graph capture)
-      int fit = scratch == nullptr ? 1 : (int)(scratch_bytes / ((int64_t)p.M * p.N * sizeof(float)));
-      p.k_splits = std::max(1, std::min(p.k_splits, fit));
-    }
-  }
-  p.partial = reinterpret_cast<float*>(scratch);
-  int rc;
-  const int sub_k = (KIND == W_INT4) ? 128 : 64;
-  const bool generic = p.perm != nullptr || p.slow_act_order || (p.num_groups > 1 && p.group_size % 128 != 0) ||
-                       (p.K % sub_k != 0) || ((int64_t)p.M * p.K * 2 >= (1ll << 31)) || ((int64_t)p.K * p.N >= (1ll << 31));
-  if (generic) rc = launch_mode<scalar_t, KIND, 2>(p, cfg, stream);
-  else if (p.num_groups > 1) rc = launch_mode<scalar_t, KIND, 1>(p, cfg, stream);
-  else rc = launch_mode<scalar_t, KIND, 0>(p, cfg, stream);
-  if (rc != NMX_OK) return rc;
-  if (p.k_splits > 1) {
-    const int64_t mn4 = (int64_t)p.M * p.N / 4;
-    splitk_reduce_kernel<scalar_t><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(
-        reinterpret_cast<scalar_t*>(p.c), p.partial, mn4, p.k_splits);
-    NMX_LAUNCH_CHECK();
-  }
-  return NMX_OK;
-}
 
 int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales, const int32_t* g_idx,
                   const int32_t* perm, void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes,
@@ -842,7 +18,7 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   NMX_CHECK(num_groups >= 1, NMX_ERR_INVALID_ARG, "b_scales must have at least one row");
   const bool has_act_order = g_idx != nullptr;
   GemmParams p;
-  p.a = a; p.b = b_q_weight; p.scales = b_scales; p.g_idx = g_idx; p.perm = perm; p.c = c; p.partial = nullptr;
+  p.a = a; p.b = b_q_weight; p.meta = nullptr; p.scales = b_scales; p.g_idx = g_idx; p.perm = perm; p.c = c; p.partial = nullptr;
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.k_splits = 1; p.slow_act_order = 0;
   if (has_act_order) {
     if (is_k_full) {

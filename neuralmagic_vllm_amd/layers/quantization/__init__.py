@@ -6,11 +6,13 @@ from neuralmagic_vllm_amd.layers.quantization.base_config import QuantizationCon
 from neuralmagic_vllm_amd.layers.quantization.fp8 import Fp8Config
 from neuralmagic_vllm_amd.layers.quantization.gptq import GPTQConfig
 from neuralmagic_vllm_amd.layers.quantization.gptq_marlin import GPTQMarlinConfig
+from neuralmagic_vllm_amd.layers.quantization.gptq_marlin_24 import GPTQMarlin24Config
 from neuralmagic_vllm_amd.layers.quantization.marlin import MarlinConfig
 
 QUANTIZATION_METHODS: Dict[str, Type[QuantizationConfig]] = {
     "awq": AWQConfig,
     "fp8": Fp8Config,
+    "gptq_marlin_24": GPTQMarlin24Config,  # before gptq_marlin / gptq: override order (__init__.py:32-36)
     "gptq": GPTQConfig,
     "gptq_marlin": GPTQMarlinConfig,  # must stay before plain gptq in override order (reference comment, __init__.py:32-36)
     "marlin": MarlinConfig,

@@ -58,6 +58,8 @@ def register() -> None:
          "int num_bits, int size_m, int size_n, int size_k, bool is_k_full) -> Tensor", ops.gptq_marlin_gemm)
     _def(c, "gptq_marlin_repack(Tensor b_q_weight, Tensor perm, int size_k, int size_n, int num_bits) -> Tensor",
          ops.gptq_marlin_repack)
+    _def(c, "gptq_marlin_24_gemm(Tensor a, Tensor b_q_weight, Tensor b_meta, Tensor b_scales, Tensor workspace, "
+         "int num_bits, int size_m, int size_n, int size_k) -> Tensor", ops.gptq_marlin_24_gemm)
     _def(c, "fp8_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor workspace, int num_bits, int size_m, "
          "int size_n, int size_k) -> Tensor", ops.fp8_marlin_gemm)
     _def(c, "gptq_gemm(Tensor a, Tensor b_q_weight, Tensor b_gptq_qzeros, Tensor b_gptq_scales, Tensor b_g_idx, "

@@ -189,6 +189,15 @@ def marlin_gemm(a, b_q_weight, b_scales, workspace, size_m, size_n, size_k):
     return gptq_marlin_gemm(a, b_q_weight, b_scales, e, e, workspace, 4, size_m, size_n, size_k, True)
 
 
+def gptq_marlin_24_gemm(a, b_q_weight, b_meta, b_scales, workspace, num_bits, size_m, size_n, size_k):
+    """marlin_24_cuda_kernel.cu:1017-1125 as arithmetic: decode the compressed 2:4 weight (kept values + CUTLASS
+    metadata + scales) to the dense fp16 matrix, then fp32-accumulated matmul, result rounded to a.dtype."""
+    from oracle import packing
+    gs = -1 if b_scales.shape[0] == 1 else size_k // b_scales.shape[0]
+    w = packing.marlin_24_decode(b_q_weight, b_meta, b_scales, num_bits, size_k, size_n, gs)
+    return matmul(a, w.to(a.dtype))
+
+
 def fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n, size_k):
     c = torch.empty((size_m, size_n), dtype=a.dtype)
     lib().orc_fp8_marlin_gemm(_p(c), _p(a.contiguous()), _p(b_q_weight.contiguous()), _p(b_scales.contiguous()),

@@ -76,11 +76,13 @@ def _marlin_perm(num_bits: int) -> np.ndarray:
     return perm.reshape(-1, len(inter))[:, inter].reshape(-1)
 
 
-def marlin_weights(q_w: torch.Tensor, size_k: int, size_n: int, num_bits: int) -> torch.Tensor:
+def marlin_weights(q_w: torch.Tensor, size_k: int, size_n: int, num_bits: int,
+                   perm: Optional[np.ndarray] = None) -> torch.Tensor:
     pf = 32 // num_bits
     q = q_w.cpu().numpy().astype(np.uint32)
     q = q.reshape(size_k // 16, 16, size_n // 16, 16).transpose(0, 2, 1, 3).reshape(size_k // 16, size_n * 16)
-    perm = _marlin_perm(num_bits)
+    if perm is None:
+        perm = _marlin_perm(num_bits)
     q = q.reshape(-1, 1024)[:, perm].reshape(size_k // 16, size_n * 16)
     q = q.reshape(size_k // 16, size_n * 16 // pf, pf)
     shifts = (np.arange(pf, dtype=np.uint32) * num_bits)[None, None, :]
@@ -113,6 +115,126 @@ def marlin_quantize(w: torch.Tensor, num_bits: int, group_size: int, act_order: 
     marlin_q_w = marlin_weights(q_w, size_k, size_n, num_bits)
     marlin_s = marlin_permute_scales(s, size_k, size_n, group_size)
     return w_ref, marlin_q_w, marlin_s, g_idx, sort_indices, rand_perm
+
+
+# ---- 2:4 sparse Marlin: marlin_24_perms.py:16-50, format_24.py:21-177, marlin_utils.py:145-198 ----
+def _marlin_24_perm(num_bits: int) -> np.ndarray:
+    out = []
+    for i in range(32):
+        col, m = i // 4, i % 4
+        perm1 = [16 * row + (col // 2) * 256 + 8 * (col % 2) + 4 * block
+                 for block in (0, 1) for row in (2 * m, 2 * m + 1, 2 * (m + 4), 2 * (m + 4) + 1)]
+        for j in range(4):
+            out.extend(p + j for p in perm1)
+    perm = np.array(out)
+    inter = np.array([0, 2, 4, 6, 1, 3, 5, 7]) if num_bits == 4 else np.array([0, 2, 1, 3])
+    return perm.reshape(-1, len(inter))[:, inter].reshape(-1)
+
+
+_SCALE_PERM_24 = [i * 8 + j for i in range(8) for j in [0, 4, 1, 5, 2, 6, 3, 7]]
+
+
+def marlin_24_permute_scales(s: torch.Tensor, size_k: int, size_n: int, group_size: int) -> torch.Tensor:
+    if group_size < size_k and group_size != -1:
+        s = s.reshape(-1, 64)[:, _SCALE_PERM_24]
+    # channel-wise: marlin_24_scale_perm_single is the identity
+    return s.reshape(-1, size_n).contiguous()
+
+
+# format_24.py:279-308 — keep the 2 largest |w| of every 4 consecutive elements (ties: argsort order)
+def mask_creator(t: torch.Tensor) -> torch.Tensor:
+    tmp = t.detach().abs().reshape(-1, 4)
+    index = torch.argsort(tmp, dim=1)[:, :2]
+    return torch.ones_like(tmp, dtype=torch.float32).scatter_(1, index, 0).reshape(t.shape)
+
+
+def _meta_reorder_offsets(m: int, meta_ncols: int) -> np.ndarray:
+    """format_24.py:21-50 for int16 meta: flat destination of meta element (row, col) in the CUTLASS
+    ColumnMajorInterleaved<2> reordered tensor."""
+    r = np.arange(m)[:, None].repeat(meta_ncols, 1)
+    c = np.arange(meta_ncols)[None, :].repeat(m, 0)
+    gx, gy = 64, 32
+    r = r // gx * gx + (r % 2) * 2 + (r % 8) // 4 + ((r % gy) % 4) // 2 * 32 + ((r % gx) // 8) * 4
+    tr = ((r % 2 == 0) & (c % 2 == 1)).astype(np.int64)
+    bl = ((r % 2 == 1) & (c % 2 == 0)).astype(np.int64)
+    r = r + tr - bl
+    c = c - (tr - bl)
+    return ((c // 2) * m * 2 + r * 2 + c % 2).reshape(-1)
+
+
+def compress_quantized_24_weight(q_24: torch.Tensor, size_k: int, size_n: int, num_bits: int):
+    """marlin_utils.py:145-166 + format_24.py:56-177. q_24 [K,N] ints with zero point 2^(b-1) on pruned slots.
+    Returns (q_comp [K/2,N] int32, meta [K/32, 2N] int16)."""
+    zp = 1 << (num_bits - 1)
+    d = (q_24.cpu().numpy().astype(np.int64) - zp).T  # [N, K]
+    n, k = d.shape
+    assert n % 32 == 0 and k % 16 == 0
+    d4 = d.reshape(n, k // 4, 4)
+    m0, m1, _, m3 = [(d4[..., i] != 0) for i in range(4)]
+    e0, e1, e2 = m0 & m1, ~m0 & m1, ~m0 & ~m1
+    idx0 = e1.astype(np.int64) | (e2.astype(np.int64) << 1)
+    idx1 = (e0 | e2 | m3).astype(np.int64) | ((e1 | ~m1).astype(np.int64) << 1)
+    s0 = np.take_along_axis(d4, idx0[..., None], -1)
+    s1 = np.take_along_axis(d4, idx1[..., None], -1)
+    comp = np.concatenate([s0, s1], -1).reshape(n, k // 2)
+    meta4 = (idx0 | (idx1 << 2)).reshape(n, k // 16, 4)
+    meta = (meta4[..., 0] | (meta4[..., 1] << 4) | (meta4[..., 2] << 8) | (meta4[..., 3] << 12)).astype(np.uint16)
+    ncols = k // 16
+    out = np.empty(n * ncols, dtype=np.uint16)
+    out[_meta_reorder_offsets(n, ncols)] = meta.reshape(-1)
+    meta_r = out.view(np.int16).reshape(ncols // 2, n * 2)  # resize_ without moving data (marlin_utils.py:162)
+    q_comp = torch.from_numpy(np.ascontiguousarray(comp.T + zp).astype(np.int32))
+    return q_comp, torch.from_numpy(meta_r.copy())
+
+
+def marlin_24_quantize(w: torch.Tensor, num_bits: int, group_size: int):
+    """marlin_utils.py:169-205 without the .cuda() hop. Returns (w_24_ref, marlin_24_q_w_comp, meta, marlin_24_s)."""
+    size_k, size_n = w.shape
+    if group_size == -1:
+        group_size = size_k
+    mask = mask_creator(w.t()).t().bool()
+    w_24 = (mask * w).contiguous()
+    w_24_ref, q_w_24, s, _, _ = quantize_weights(w_24, num_bits, group_size, False)
+    q_comp, meta = compress_quantized_24_weight(q_w_24, size_k, size_n, num_bits)
+    mq = marlin_weights(q_comp, size_k // 2, size_n, num_bits, _marlin_24_perm(num_bits))
+    ms = marlin_24_permute_scales(s, size_k, size_n, group_size)
+    return w_24_ref, mq, meta, ms
+
+
+def marlin_24_decode(mq: torch.Tensor, meta: torch.Tensor, ms: torch.Tensor, num_bits: int, size_k: int, size_n: int,
+                     group_size: int) -> torch.Tensor:
+    """Inverse of marlin_24_quantize's packing: kernel-format tensors -> dense fp16 W [K,N] (what
+    gptq_marlin_24_gemm multiplies by; marlin_24_cuda_kernel.cu:111-860 read as a data format)."""
+    pf = 32 // num_bits
+    zp = 1 << (num_bits - 1)
+    kc = size_k // 2
+    v = mq.cpu().numpy().astype(np.uint32)
+    shifts = (np.arange(pf, dtype=np.uint32) * num_bits)[None, None, :]
+    q = ((v[:, :, None] >> shifts) & (2**num_bits - 1)).reshape(kc // 16, size_n * 16).astype(np.int64)
+    perm = _marlin_24_perm(num_bits)
+    tiles = np.empty_like(q).reshape(-1, 1024)
+    tiles[:, perm] = q.reshape(-1, 1024)
+    comp = tiles.reshape(kc // 16, size_n // 16, 16, 16).transpose(0, 2, 1, 3).reshape(kc, size_n)  # [K/2, N]
+    comp = comp.T - zp  # [N, K/2]
+    ncols = size_k // 16
+    flat = meta.cpu().numpy().reshape(-1).view(np.uint16).astype(np.int64)
+    m = flat[_meta_reorder_offsets(size_n, ncols)].reshape(size_n, ncols)
+    nib = np.stack([(m >> (4 * i)) & 15 for i in range(4)], -1).reshape(size_n, size_k // 4)
+    dense = np.zeros((size_n, size_k // 4, 4), dtype=np.int64)
+    c2 = comp.reshape(size_n, size_k // 4, 2)
+    np.put_along_axis(dense, (nib & 3)[..., None], c2[..., 0:1], -1)
+    # second value last so that (degenerate) equal indices resolve like the hardware: later element wins is
+    # irrelevant for valid 2:4 metadata (idx0 < idx1 always)
+    np.put_along_axis(dense, (nib >> 2)[..., None], c2[..., 1:2], -1)
+    dq = torch.from_numpy(dense.reshape(size_n, size_k).T.copy()).half()  # [K,N] q - zp
+    if group_size == -1:
+        group_size = size_k
+    if group_size < size_k:
+        inv = np.argsort(np.array(_SCALE_PERM_24))
+        s = ms.reshape(-1, 64)[:, inv].reshape(-1, size_n)
+    else:
+        s = ms.reshape(-1, size_n)
+    return (dq.reshape(size_k // group_size, group_size, size_n) * s[:, None, :]).reshape(size_k, size_n)
 
 
 # marlin_utils.py:226-247

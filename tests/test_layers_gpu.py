@@ -77,6 +77,34 @@ def test_marlin_checkpoint_method():
         MarlinConfig(64)
 
 
+@pytest.mark.parametrize("bits,group", [(4, 128), (8, -1)])
+def test_gptq_marlin_24_method(bits, group):
+    from neuralmagic_vllm_amd.layers.quantization import get_quantization_config
+    from neuralmagic_vllm_amd.layers.quantization.gptq_marlin_24 import GPTQMarlin24Config
+    assert get_quantization_config("gptq_marlin_24") is GPTQMarlin24Config
+    assert GPTQMarlin24Config.override_quantization_method({"checkpoint_format": "marlin_24"}, None) == "gptq_marlin_24"
+    seed_all(2)
+    K, N = 256, 512
+    cfg = GPTQMarlin24Config.from_config({"bits": bits, "group_size": group})
+    method = cfg.get_quant_method(None)
+    layer = Layer()
+    method.create_weights(layer, K, [N], K, N, torch.float16, device=DEV)
+    assert layer.B_24.shape == (K // 32, N * 16 // (32 // bits)) and layer.B_meta.shape == (K // 32, 2 * N)
+    assert layer.workspace.numel() == N // 128 * 64
+    w = torch.randn(K, N, dtype=torch.float16)
+    w_ref, mq, meta, ms = packing.marlin_24_quantize(w, bits, group)
+    load(layer, B_24=mq.to(DEV), B_meta=meta.to(DEV), s=ms.to(DEV))
+    x = torch.randn(3, 5, K, dtype=torch.float16)
+    bias = torch.randn(N, dtype=torch.float16)
+    out = method.apply(layer, x.to(DEV), bias.to(DEV))
+    ref = x.float() @ w_ref.float() + bias.float()
+    assert out.shape == (3, 5, N) and compute_max_diff(out.cpu(), ref) < 1e-3
+    with pytest.raises(ValueError):
+        GPTQMarlin24Config(4, 64)
+    with pytest.raises(ValueError):
+        method.create_weights(Layer(), K, [N], K, N, torch.bfloat16, device=DEV)
+
+
 @pytest.mark.parametrize("m", [4, 300])
 def test_awq_method(m):
     from neuralmagic_vllm_amd.layers.quantization.awq import AWQConfig

@@ -129,6 +129,36 @@ def test_marlin_unpack_and_gemm_oracle(name):
     assert err < 1e-3, err  # only fp16 output rounding separates the two
 
 
+MARLIN24_CASES = ["marlin24_b4_g-1", "marlin24_b4_g128", "marlin24_b8_g128"]
+
+
+@pytest.mark.parametrize("name", MARLIN24_CASES)
+def test_marlin_24_restatement_matches_reference_utils(name):
+    """2:4 pipeline (mask_creator -> quantize -> CUTLASS compress + meta reorder -> Marlin-24 permutation) restated
+    in numpy is bit-identical to the reference's utilities on the same weights, and the inverse (decode) recovers
+    the reference's w_24_ref exactly; the oracle GEMM then matches the reference's a @ w_24_ref."""
+    g = load_golden(name)
+    bits, gs = int(g["bits"]), int(g["group_size"])
+    w = from_bits(g["w"], torch.float16)
+    K, N = w.shape
+    mask = packing.mask_creator(w.t()).t().bool()
+    assert np.array_equal(mask.numpy(), g["mask"])
+    w_ref, mq, meta, ms = packing.marlin_24_quantize(w, bits, gs)
+    assert np.array_equal(w_ref.view(torch.int16).numpy().view(np.uint16), g["w_24_ref"])
+    assert np.array_equal(mq.numpy(), g["marlin_24_q"])
+    assert np.array_equal(meta.numpy(), g["meta"])
+    assert np.array_equal(ms.view(torch.int16).numpy().view(np.uint16), g["marlin_24_s"])
+    wd = packing.marlin_24_decode(torch.from_numpy(g["marlin_24_q"]), torch.from_numpy(g["meta"]),
+                                  from_bits(g["marlin_24_s"], torch.float16), bits, K, N, gs)
+    assert np.array_equal(wd.view(torch.int16).numpy().view(np.uint16), g["w_24_ref"])
+    a = from_bits(g["a"], torch.float16)
+    c = oracle.gptq_marlin_24_gemm(a, torch.from_numpy(g["marlin_24_q"]), torch.from_numpy(g["meta"]),
+                                   from_bits(g["marlin_24_s"], torch.float16), None, bits, a.shape[0], N, K)
+    c_ref = torch.from_numpy(g["c_ref"])
+    err = float((c.float() - c_ref).abs().mean() / c_ref.abs().mean())
+    assert err < 1e-3, err
+
+
 def test_pack_fp8_matches_reference():
     g = load_golden("pack_fp8")
     w8 = torch.from_numpy(g["w8"]).view(torch.float8_e4m3fn)
