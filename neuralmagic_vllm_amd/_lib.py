@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmx_hip.so")
+# NMX_LIB_PATH: load another build of the same HIP library (kernel experiments); never a non-HIP substitute
+LIB_PATH = os.environ.get("NMX_LIB_PATH") or os.path.join(_HERE, "libnmx_hip.so")
 
 _lib = None
 

@@ -28,6 +28,13 @@
 
 namespace {
 
+// Timing ablations for tools/ablate_gemm.sh (results are WRONG when set; never defined in the product build):
+// bit 0 skip MFMAs, 1 skip dequant, 2 skip LDS fragment reads, 3 skip workgroup barriers, 4 skip weight waits,
+// bit 5 skip the epilogue stores, 6 skip activation loads, 7 skip weight loads, 8 skip LDS fragment writes
+#ifndef NMX_ABLATE
+#define NMX_ABLATE 0
+#endif
+
 constexpr int kSubSteps = 4;  // 32-k steps per activation staging sub-chunk (128 k)
 
 enum WeightKind { W_INT4 = 0, W_INT8 = 1, W_FP8 = 2 };
@@ -208,15 +215,21 @@ struct GemmParams {
 // pair holds, for each of its four 16-column tiles, the two kept values of quads g and g + 4 of the k-tile, and the
 // hardware sparse MFMA (v_smfmac_f32_16x16x32_f16) consumes them directly together with the 2-bit positions from
 // the metadata tensor: the compressed operand is never expanded. Second ring slot = the lane's 16 B of metadata.
-template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP = false>
-__global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
+// Second launch bound = minimum waves per SIMD: without it hipcc spreads the MT = 4 accumulators over VGPRs + AGPRs
+// (> 256 registers) and a CU holds ONE workgroup, so every stall of a wave is exposed and a grid just above 256
+// workgroups runs as two rounds.
+// W8 = true: 8 waves per workgroup (twice the K slices for the same column groups): two waves per SIMD are then
+// resident BY CONSTRUCTION and fill each other's stalls, without doubling the cross-workgroup K splits (and their
+// fp32 partial traffic) that two co-resident 4-wave workgroups would need.
+template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const GemmParams p) {
   static_assert(!SP || (__is_same(scalar_t, f16) && KIND != W_FP8), "2:4 path: fp16, int4 / int8 weights");
   constexpr bool I4 = (KIND == W_INT4);
   constexpr bool GENERIC = (MODE == 2);
   constexpr int SUB = I4 ? 4 : 2;                     // 32-k steps per sub-chunk
   constexpr int PF = 2 * SUB;                         // k-steps of weights in flight per wave
   constexpr int NTILE = 4;                            // 16-column MFMA tiles per wave (one 64-column group)
-  constexpr int KW = 4 / NG;                          // K slices per workgroup
+  constexpr int KW = (W8 ? 8 : 4) / NG;               // K slices per workgroup
   constexpr int ROWS = 16 * MT;
   constexpr int WORDS64 = I4 ? 128 : 256;             // int32 per (k-tile, 64-column group)
   constexpr int ABUF = SUB * 4 * ROWS * 16;           // bytes of one activation buffer
@@ -364,7 +377,8 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
     }
   };
   auto sync_slice = [&]() {
-    if constexpr (NG > 1) __syncthreads();
+    if constexpr ((NMX_ABLATE & 8) != 0) __builtin_amdgcn_wave_barrier();
+    else if constexpr (NG > 1) __syncthreads();
     else __builtin_amdgcn_wave_barrier();  // wave-private buffer: LDS ops of one wave complete in order
   };
 
@@ -388,8 +402,10 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
     }
     u32x4 af[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      af[mt] = *reinterpret_cast<const u32x4*>(abuf + (((ksl * 4 + g) * ROWS + mt * 16 + li) * 16));
+    for (int mt = 0; mt < MT; ++mt) {
+      if constexpr ((NMX_ABLATE & 4) != 0) af[mt] = u32x4{(uint32_t)lane, (uint32_t)ksl, (uint32_t)mt, 0x3c003c00u};
+      else af[mt] = *reinterpret_cast<const u32x4*>(abuf + (((ksl * 4 + g) * ROWS + mt * 16 + li) * 16));
+    }
 
     if constexpr (SP) {
       // index registers: byte 0 (ABID 0) = positions for tile 2 p, byte 2 (ABID 2) = tile 2 p + 1; low nibble = quad
@@ -435,7 +451,9 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
       }
       uint32_t d0, d1, d2, d3;
       u32x4 wf;
-      if (!slow_act) {
+      if constexpr ((NMX_ABLATE & 2) != 0) {
+        wf = u32x4{w0, w1, w0 ^ s2[t], w1};
+      } else if (!slow_act) {
         Dequant<scalar_t, KIND>::run(w0, s2[t], grouped && GA == 0, d0, d1);
         Dequant<scalar_t, KIND>::run(w1, s2[t], grouped && GA == 0, d2, d3);
         wf = u32x4{d0, d1, d2, d3};
@@ -459,6 +477,10 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        if constexpr ((NMX_ABLATE & 1) != 0) {
+          acc[mt][t][0] += __builtin_bit_cast(float, wf[mt & 3] ^ af[mt][t & 3]);
+          continue;
+        }
         if constexpr (GA == 0) acc[mt][t] = mfma_16x16x32<scalar_t>(wf, af[mt], acc[mt][t]);
         else if constexpr (GA == 1) gacc[ACC_SCALE ? mt : 0][t] = mfma_16x16x32<scalar_t>(wf, af[mt], f32x4{0.f, 0.f, 0.f, 0.f});
         else gacc[ACC_SCALE ? mt : 0][t] = mfma_16x16x32<scalar_t>(wf, af[mt], gacc[ACC_SCALE ? mt : 0][t]);
@@ -502,27 +524,37 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
   } else {
     // ---- hand-counted loop: every vector-memory op is an inline-asm load issued in a fixed periodic pattern, so
     // that every wait is a COUNTED s_waitcnt vmcnt(N) and PF k-steps of weights stay in flight per wave.
-    // Issue order per sub-chunk body:  [batch: PIECES activation loads (+1 scale row) for the NEXT sub-chunk]
-    //                                  then per k-step [wait weights(kstep)] [load weights(kstep + PF)] [compute].
-    // Ops younger than weights(kstep) at its wait: (PF - 1) weight loads + 2 batches  -> vmcnt(PF - 1 + 2 BATCH).
-    // Ops younger than the batch at the end of the body: SUB weight loads           -> vmcnt(SUB).
+    // Issue order per sub-chunk body:  [batch: PIECES activation loads (+ scale rows) for sub-chunk sub + AD]
+    //                                  then per k-step [wait weights(kstep)] [compute] [load weights(kstep + PF)],
+    //                                  then [wait batch(sub + 1)] [write it to LDS] [barrier].
+    // The activation tile is requested AD = 2 sub-chunks ahead (two register sets): an L2 round trip under a full
+    // weight stream is ~1 us, about what a whole sub-chunk of compute takes, and with AD = 1 every iteration ended
+    // on that latency (measured: a kernel with all compute removed still took 55 % of the full time).
+    // Ops younger than weights(kstep) at its wait: 2 (PF - 1) weight loads + 2 batches -> vmcnt(2 PF - 2 + 2 BATCH).
+    // Ops younger than batch(sub + 1) at the end of body `sub`: the weight loads of AD bodies + (AD - 1) batches.
     // (vmcnt(N) with N <= #younger ops is always safe; loads past the range are clamped, never skipped, so the
     // pattern is the same in every iteration, prologue included.)
+    constexpr int AD = 2;
     constexpr int NSC = (MODE == 1) ? (ACC_SCALE ? 4 : 1) : 0;  // scale loads per batch
     constexpr int BATCH = PIECES + NSC;
     constexpr int WAIT_B = 2 * PF - 2 + 2 * BATCH;   // weight loads are 2 instructions per k-step
-    constexpr int WAIT_BATCH = 2 * SUB;
-    static_assert(WAIT_B < 60, "vmcnt is 6 bits");
+    constexpr int WAIT_BATCH = AD * 2 * SUB + (AD - 1) * BATCH;
+    static_assert(WAIT_B < 60 && WAIT_BATCH < 60, "vmcnt is 6 bits");
     BStep ring[PF];
-    ARegs areg;
-    u32x2 sraw[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    ARegs areg[AD];
+    u32x2 sraw[AD][4];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       ring[i].q0 = bvec_t{};
       ring[i].q1 = mvec_t{};
     }
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) areg.v[i] = u32x4{0, 0, 0, 0};
+    for (int d = 0; d < AD; ++d) {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) areg[d].v[i] = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sraw[d][i] = u32x2{0, 0};
+    }
 
     // fast modes require K % (32 SUB) == 0, so every k-tile row of an in-range k-step exists; rows past the end of
     // the matrix (prefetch beyond the slice) are out of the descriptor's range and read as zeros
@@ -534,6 +566,7 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
     const int b_voff = (int)((bw - p.b) * 4);
     const int m_voff = (int)(meta_off * 2);
     auto issue_b = [&](int kstep, BStep& r) {
+      if constexpr ((NMX_ABLATE & 128) != 0) return;
       if constexpr (SP) {
         if constexpr (I4) buf_load_x2(r.q0, b_voff, rs_b, kstep * row_bytes);
         else buf_load_x4(r.q0, b_voff, rs_b, kstep * row_bytes);
@@ -566,20 +599,24 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
     // position 8 (4 (g&1) + r) + 4 (g>>1) + x: four 8-byte loads (r = 0..3), x contiguous
     const int s_voff = ACC_SCALE ? (int)((((col_ok ? n0 : 0) / 64) * 64 + 32 * (g & 1) + 4 * (g >> 1)) * sizeof(scalar_t))
                                  : (int)(scale_off * sizeof(scalar_t));
-    auto issue_batch = [&](int sub) {
+    auto issue_batch = [&](int sub, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
       const int kbase = sub * (SUB * 32);
       const int soff = kbase * (int)sizeof(scalar_t);  // wave-uniform
+      if constexpr ((NMX_ABLATE & 64) == 0) {
 #pragma unroll
-      for (int it = 0; it < PIECES; ++it) buf_load_x4(areg.v[it], a_voff[it], rs_a, soff);
+        for (int it = 0; it < PIECES; ++it) buf_load_x4(areg[SET].v[it], a_voff[it], rs_a, soff);
+      }
       if constexpr (MODE == 1) {
         const int grp = min(kbase / p.group_size, p.num_groups - 1);
 #pragma unroll
         for (int r = 0; r < NSC; ++r)
-          buf_load_x2(sraw[r], s_voff + 8 * r * (int)sizeof(scalar_t), rs_s, grp * N * (int)sizeof(scalar_t));
+          buf_load_x2(sraw[SET][r], s_voff + 8 * r * (int)sizeof(scalar_t), rs_s, grp * N * (int)sizeof(scalar_t));
       }
     };
     // make the landed batch usable: zero the out-of-range pieces, write the fragments, unpack the scales
-    auto land_batch = [&](int sub, bool valid, char* buf) {
+    auto land_batch = [&](int sub, bool valid, char* buf, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
       const int kbase = sub * (SUB * 32);
 #pragma unroll
       for (int it = 0; it < PIECES; ++it) {
@@ -587,20 +624,20 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
         const int row = piece / (SUB * 4);
         const int cc16 = piece % (SUB * 4);
         const bool ok = valid && piece < NPIECE && (m0 + row) < M && (kbase + cc16 * 8) < K;
-        areg.v[it] = ok ? areg.v[it] : u32x4{0, 0, 0, 0};
+        areg[SET].v[it] = ok ? areg[SET].v[it] : u32x4{0, 0, 0, 0};
       }
-      store_a(areg, buf);
+      if constexpr ((NMX_ABLATE & 256) == 0) store_a(areg[SET], buf);
       if constexpr (ACC_SCALE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           union { u32x2 v; scalar_t e[4]; } raw;
-          raw.v = sraw[r];
+          raw.v = sraw[SET][r];
 #pragma unroll
           for (int t = 0; t < NTILE; ++t) srow[t][r] = Scalar<scalar_t>::to_f32(raw.e[t]);
         }
       } else if constexpr (MODE == 1) {
         union { u32x2 v; scalar_t e[4]; } raw;
-        raw.v = sraw[0];
+        raw.v = sraw[SET][0];
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
           const scalar_t sv = raw.e[t];
@@ -615,33 +652,39 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
         }
       }
     };
-    auto wait_batch = [&]() {
+    auto wait_batch = [&](auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
+      ARegs& ar = areg[SET];
+      u32x2(&sr)[4] = sraw[SET];
       // binds every batch destination so that no use can be scheduled above the wait
       if constexpr (PIECES == 1)
-        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(areg.v[0]), "+v"(sraw[0]), "+v"(sraw[1]), "+v"(sraw[2]), "+v"(sraw[3])
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ar.v[0]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])
                      : "n"(WAIT_BATCH) : "memory");
       else if constexpr (PIECES == 2)
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(areg.v[0]), "+v"(areg.v[1]), "+v"(sraw[0]), "+v"(sraw[1]), "+v"(sraw[2]), "+v"(sraw[3])
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])
                      : "n"(WAIT_BATCH) : "memory");
       else
-        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(areg.v[0]), "+v"(areg.v[1]), "+v"(areg.v[2]), "+v"(areg.v[3]), "+v"(sraw[0]),
-                     "+v"(sraw[1]), "+v"(sraw[2]), "+v"(sraw[3]) : "n"(WAIT_BATCH) : "memory");
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(sr[0]),
+                     "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]) : "n"(WAIT_BATCH) : "memory");
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
     static_assert(PIECES == 1 || PIECES == 2 || PIECES == 4, "unsupported activation piece count");
     auto wait_b = [&](BStep& r) {
+      if constexpr ((NMX_ABLATE & 16) != 0) return;
       asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.q0), "+v"(r.q1) : "n"(WAIT_B) : "memory");
     };
 
     if (n_iter > 0) {
       // prologue in the steady-state pattern: [batch] [SUB weight loads] [batch] [SUB weight loads]
-      issue_batch(sub_begin);
+      issue_batch(sub_begin, S0{});
 #pragma unroll
       for (int i = 0; i < SUB; ++i) issue_b(sub_begin * SUB + i, ring[i]);
-      issue_batch(sub_begin);
+      issue_batch(sub_begin + 1, S1{});
 #pragma unroll
       for (int i = SUB; i < PF; ++i) issue_b(sub_begin * SUB + i, ring[i]);
-      wait_batch();
-      land_batch(sub_begin, sub_begin < sub_end, lds_a);
+      wait_batch(S0{});
+      land_batch(sub_begin, sub_begin < sub_end, lds_a, S0{});
     }
     sync_slice();
 
@@ -649,7 +692,7 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
       constexpr int PAR = decltype(par_c)::value;
       const int sub = sub_begin + it;
       const bool have_next = ((sub + 1) < sub_end) && (it + 1 < n_iter);
-      issue_batch(sub + 1);
+      issue_batch(sub + 2, std::integral_constant<int, PAR>{});
 #pragma unroll
       for (int ksl = 0; ksl < SUB; ++ksl) {
         const int kstep = sub * SUB + ksl;
@@ -668,8 +711,8 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][t][r] += srow[t][r] * gacc[mt][t][r];
       }
-      wait_batch();
-      land_batch(sub + 1, have_next, lds_a + (PAR ^ 1) * ABUF);
+      wait_batch(std::integral_constant<int, PAR ^ 1>{});
+      land_batch(sub + 1, have_next, lds_a + (PAR ^ 1) * ABUF, std::integral_constant<int, PAR ^ 1>{});
       sync_slice();
     };
     for (int it = 0; it < n_iter; it += 2) {
@@ -737,6 +780,9 @@ __global__ __launch_bounds__(256) void marlin_gemm_kernel(const GemmParams p) {
     }
   }
   if (kslice != 0 || !col_ok) return;
+  if constexpr ((NMX_ABLATE & 32) != 0) {
+    if (acc[0][0][0] != 12345.678f) return;
+  }
 
   if constexpr (SP) {
     // lane (g, li): D row r of tile x = 2 p + q is column 8 (4 (g & 1) + r) + 2 (g >> 1) + p + 4 q: tiles q and 2 + q
@@ -838,54 +884,81 @@ __global__ void marlin_repack_kernel(const uint32_t* __restrict__ in, const int3
   out[idx] = r;
 }
 
-struct GemmCfg { int mt, ng, splits; };
+struct GemmCfg { int mt, ng, splits, w8; };
 
-// Tile shape by M; K splits so that the grid fills the chip (~2 workgroups per CU) while the fp32 partial traffic
-// (splits * M * N * 8 bytes written + read) stays below about half of the weight bytes.
+// Tile shape and K splits, fitted to MI355X sweeps (tools/gemm_sweep.py, tools/check_cfg.py; Llama-3-8B and 70B/TP8
+// shapes). What the measurements say:
+//  * every wave is instruction-issue bound (dequant VALU + MFMA issue, ~450 cycles per 32-k step at MT = 4), so time
+//    ~ k-steps per wave once every CU has work; a dependent split-K reduce launch costs ~4-5 us, a workgroup's
+//    prologue + epilogue ~5 us;
+//  * M <= 16: 4 waves split K inside the workgroup; split across workgroups only when a wave would run more than
+//    ~32 k-steps or fewer than ~128 workgroups exist;
+//  * 16 < M <= 64 and N < 16 K: 32-row tiles (two row blocks re-read the weights through L2) beat one 64-row tile -
+//    twice the workgroups, half the accumulators, fp32 group scaling;
+//  * otherwise 64-row x 256-column tiles with 8 waves (2 K slices) per workgroup.
 GemmCfg pick_cfg(int M, int N, int K) {
   GemmCfg c;
+  c.w8 = 0;
+  const int n64 = N / 64;
   if (M <= 16) { c.mt = 1; c.ng = 1; }
-  else if (M <= 32) { c.mt = 2; c.ng = 2; }
-  else { c.mt = 4; c.ng = 4; }
-  if (const char* e = getenv("NMX_GEMM_CFG")) {  // tuning override: "mt,ng,splits"
-    int a = 0, b = 0, s = 0;
-    if (sscanf(e, "%d,%d,%d", &a, &b, &s) == 3 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && s >= 1 && !(a == 4 && b != 4) && !(a == 2 && b == 1)) {
+  else if (M <= 32 || (M <= 64 && n64 < 256)) { c.mt = 2; c.ng = 2; }
+  else { c.mt = 4; c.ng = 4; c.w8 = 1; }
+  if (const char* e = getenv("NMX_GEMM_CFG")) {  // tuning override: "mt,ng,splits[,w8]"
+    int a = 0, b = 0, s = 0, w = 0;
+    const int got = sscanf(e, "%d,%d,%d,%d", &a, &b, &s, &w);
+    if (got >= 3 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && s >= 1 && !(a == 4 && b != 4) && !(a == 2 && b == 1)) {
       c.mt = a; c.ng = b; c.splits = s;
+      c.w8 = (got == 4 && w != 0 && a == 4) ? 1 : 0;
       return c;
     }
   }
-  // measured on MI355X (tools/gemm_sweep.py): ~384 workgroups of the narrow tiles / ~256 of the wide ones fill the
-  // chip; more K splits only add partial-sum traffic and a longer reduce
-  const int n_tiles = ceil_div(N, 64 * c.ng);
-  const int m_blocks = ceil_div(M, 16 * c.mt);
-  const int kw = 4 / c.ng;
-  const int total_sub = ceil_div(ceil_div(K, 32), 4);
-  const int target = (c.ng == 4) ? 256 : 384;
-  int splits = (n_tiles * m_blocks >= target) ? 1 : ceil_div(target, n_tiles * m_blocks);
-  const int cap_work = std::max(1, total_sub / (2 * kw));  // >= 2 sub-chunks per K-slice
-  splits = std::max(1, std::min(splits, std::min(cap_work, 16)));
-  c.splits = splits;
+  const int kw = (c.w8 ? 8 : 4) / c.ng;
+  const int total_steps = ceil_div(K, 32);
+  const int total_sub = ceil_div(total_steps, 4);
+  const int units = ceil_div(N, 64 * c.ng) * ceil_div(M, 16 * c.mt);
+  auto friendly = [&](int s) { return s == 1 || total_sub % (s * kw) == 0; };  // equal K slices
+  auto ks = [&](int s) { return total_steps / (s * kw); };                      // k-steps per wave
+  int sp = 1;
+  if (c.mt == 1) {
+    int want = std::max(1, (ks(1) + 16) / 32);
+    if (units < 64) {
+      for (int s = 1; s <= 16; ++s)
+        if (friendly(s) && units * s >= 128 && ks(s) >= 8) { want = std::max(want, s); break; }
+    }
+    for (int s = 1; s <= std::min(want, 16); ++s)
+      if (friendly(s)) sp = s;
+  } else if (units < 200) {
+    const int cap = c.w8 ? 256 : 512;  // workgroups resident at once
+    for (int s = 1; s <= 8; ++s)
+      if (friendly(s) && ks(s) >= 16 && units * s <= cap) sp = s;
+    if (units * sp < 192) {
+      for (int s = sp + 1; s <= 16; ++s)
+        if (friendly(s) && ks(s) >= 8 && units * s >= 256) { if (units * s <= cap) sp = s; break; }
+    }
+  }
+  c.splits = sp;
   return c;
 }
 
-template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP>
+template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP, bool W8 = false>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr int SUB = (KIND == W_INT4) ? 4 : 2;
-  constexpr int KW = 4 / NG;
+  constexpr int KW = (W8 ? 8 : 4) / NG;
   const size_t stage = (size_t)KW * 2 * SUB * 4 * (16 * MT) * 16;
   const size_t red = (KW > 1) ? (size_t)(KW / 2) * NG * MT * 4 * 64 * 4 * sizeof(float) : 0;
   const size_t smem = std::max(stage, red);
   dim3 grid(ceil_div(p.N, 64 * NG), p.k_splits, ceil_div(p.M, 16 * MT));
-  auto kern = marlin_gemm_kernel<scalar_t, KIND, MT, NG, MODE, SP>;
+  auto kern = marlin_gemm_kernel<scalar_t, KIND, MT, NG, MODE, SP, W8>;
   if (smem > 64 * 1024)
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  kern<<<grid, 256, smem, stream>>>(p);
+  kern<<<grid, W8 ? 512 : 256, smem, stream>>>(p);
   NMX_LAUNCH_CHECK();
   return NMX_OK;
 }
 
 template <typename scalar_t, int KIND, int MODE, bool SP>
 int launch_mode(const GemmParams& p, const GemmCfg& cfg, hipStream_t stream) {
+  if (cfg.w8) return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP, true>(p, stream);
   if (cfg.mt == 1 && cfg.ng == 1) return launch_cfg<scalar_t, KIND, 1, 1, MODE, SP>(p, stream);
   if (cfg.mt == 1 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 1, 2, MODE, SP>(p, stream);
   if (cfg.mt == 1) return launch_cfg<scalar_t, KIND, 1, 4, MODE, SP>(p, stream);

@@ -18,15 +18,19 @@ REPS = 10
 
 def configs():
     cfgs = []
-    for M in (1, 16, 64):
-        for name in ("qkv", "gate_up", "down"):
+    for M in (1, 16, 32, 64):
+        for name in ("qkv", "o", "gate_up", "down"):
             if M <= 16:
                 for mt, ng in ((1, 1), (1, 2), (1, 4)):
-                    for sp in (1, 2, 4, 8):
+                    for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+                        cfgs.append((name, M, mt, ng, sp))
+            elif M <= 32:
+                for mt, ng in ((2, 2), (2, 4)):
+                    for sp in (1, 2, 3, 4, 6, 8, 12, 16):
                         cfgs.append((name, M, mt, ng, sp))
             else:
-                for mt, ng in ((4, 4), (4, 2), (2, 2), (2, 4)):
-                    for sp in (1, 2, 4, 8, 16):
+                for mt, ng in ((4, 4), (2, 2), (2, 4)):
+                    for sp in (1, 2, 3, 4, 6, 8, 12, 16):
                         cfgs.append((name, M, mt, ng, sp))
     return cfgs
 
