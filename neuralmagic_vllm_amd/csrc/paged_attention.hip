@@ -389,6 +389,156 @@ __global__ void paged_attention_v2_reduce_kernel(scalar_t* __restrict__ out, con
   }
 }
 
+// ---- float32 queries / float32 or fp8 cache (attention_kernels.cu:742-803 instantiates `float` too) -------------
+// A plain VALU kernel - fp32 has no fast MFMA shape and the dtype only appears in tests and debugging runs, so it is
+// written for clarity: one workgroup per (query head, sequence[, partition]); a wave takes 64 tokens at a time, one
+// token per lane for q.k (a lane's loads walk the 16-byte K chunks of its token, coalesced across the lanes of a
+// block), online softmax over the wave's tiles, then one head dimension per lane for P.V (V rows are contiguous
+// over the tokens of a block). The four waves are merged through LDS like the MFMA kernel's.
+template <int KV>
+__global__ __launch_bounds__(256) void paged_attention_f32_kernel(const AttnParams p, int D) {
+  constexpr bool FP8 = (KV != NMX_KV_AUTO);
+  using cache_t = typename std::conditional<FP8, uint8_t, float>::type;
+  constexpr int X = FP8 ? 16 : 4;  // elements per 16-byte K chunk
+  constexpr int NW = 4;
+  const int head = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
+  const int seq_len = p.seq_lens[seq];
+  int tok_begin = 0, tok_end = seq_len;
+  if (p.partitioned) {
+    tok_begin = part * kPartitionSize;
+    if (tok_begin >= seq_len) return;
+    tok_end = min(seq_len, tok_begin + kPartitionSize);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kvh = head / p.q_per_kv;
+  const int BS = p.block_size;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* q_s = reinterpret_cast<float*>(smem);             // [D]
+  float* p_s = q_s + ((D + 3) & ~3);                       // [NW][64]
+  float* m_s = p_s + NW * 64;                              // [NW]
+  float* l_s = m_s + NW;                                   // [NW]
+  float* o_s = l_s + NW;                                   // [NW][D]
+  const float* qp = reinterpret_cast<const float*>(p.q) + (int64_t)seq * p.q_stride + (int64_t)head * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) q_s[d] = qp[d];
+  __syncthreads();
+
+  const float slope = p.alibi_slopes != nullptr ? p.alibi_slopes[head] : 0.f;
+  int bs_block_offset = 0, q_bs_block_id = 0;
+  if (p.sparse) {
+    q_bs_block_id = (seq_len - 1) / p.bs_block_size;
+    if (p.bs_head_sliding_step >= 0) bs_block_offset = (p.tp_rank * p.num_heads + head) * p.bs_head_sliding_step + 1;
+    else bs_block_offset = (p.tp_rank * p.num_kv_heads + kvh) * (-p.bs_head_sliding_step) + 1;
+  }
+  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  const cache_t* kc = reinterpret_cast<const cache_t*>(p.k_cache) + (int64_t)kvh * p.kv_head_stride;
+  const cache_t* vc = reinterpret_cast<const cache_t*>(p.v_cache) + (int64_t)kvh * p.kv_head_stride;
+  auto ld = [&](const cache_t* ptr) -> float {
+    if constexpr (FP8) return fp8_to_f32<KV>(*ptr) * p.kv_scale;
+    else return *ptr;
+  };
+
+  float m_run = -FLT_MAX, l_run = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // d = lane + 64 j
+  float* pw = p_s + wave * 64;
+  for (int t0 = tok_begin + wave * 64; t0 < tok_end; t0 += NW * 64) {
+    const int tok = t0 + lane;
+    const bool valid = tok < tok_end;
+    const int blk = tok >> p.bs_shift, off = tok & (BS - 1);
+    const int64_t phys = valid ? (int64_t)bt[blk] : 0;
+    float dot = 0.f;
+    if (valid) {
+      const cache_t* kb = kc + phys * p.kv_block_stride + (int64_t)off * X;
+      for (int c = 0; c < D / X; ++c) {
+#pragma unroll
+        for (int e = 0; e < X; ++e) dot += q_s[c * X + e] * ld(kb + (int64_t)c * BS * X + e);
+      }
+    }
+    float logit = p.scale * dot + ((slope != 0.f) ? slope * (float)(tok - seq_len + 1) : 0.f);
+    bool masked = !valid;
+    if (p.sparse) {
+      const int kb_id = (blk * BS) / p.bs_block_size;
+      const bool is_remote = ((kb_id + bs_block_offset) % p.bs_vert_stride) == 0;
+      const bool is_local = kb_id > q_bs_block_id - p.bs_local_blocks;
+      masked = masked || !(is_remote || is_local);
+    }
+    const float m_new = fmaxf(m_run, wave_reduce_max(masked ? -FLT_MAX : logit));
+    const float pv = (masked || m_new == -FLT_MAX) ? 0.f : __expf(logit - m_new);
+    const float alpha = (m_run == -FLT_MAX) ? 0.f : __expf(m_run - m_new);
+    l_run = l_run * alpha + wave_reduce_sum(pv);
+    m_run = m_new;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] *= alpha;
+    pw[lane] = pv;
+    __builtin_amdgcn_wave_barrier();
+    const int ntok = min(64, tok_end - t0);
+    for (int b0 = 0; b0 < ntok; b0 += BS) {
+      const int64_t pb = (int64_t)bt[(t0 + b0) >> p.bs_shift];
+      const int nb = min(BS, ntok - b0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d = lane + 64 * j;
+        if (d < D) {
+          const cache_t* vr = vc + pb * p.kv_block_stride + (int64_t)d * BS;
+          float a = acc[j];
+          for (int o = 0; o < nb; ++o) a += pw[b0 + o] * ld(vr + o);
+          acc[j] = a;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    m_s[wave] = m_run;
+    l_s[wave] = l_run;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (lane + 64 * j < D) o_s[wave * D + lane + 64 * j] = acc[j];
+  __syncthreads();
+  float M = -FLT_MAX;
+  for (int w = 0; w < NW; ++w) M = fmaxf(M, m_s[w]);
+  float f[NW], L = 0.f;
+  for (int w = 0; w < NW; ++w) {
+    f[w] = (m_s[w] == -FLT_MAX) ? 0.f : __expf(m_s[w] - M);
+    L += l_s[w] * f[w];
+  }
+  const float inv = __fdividef(1.f, L + 1e-6f);
+  float* outp;
+  if (p.partitioned) {
+    const int64_t pidx = ((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part;
+    outp = reinterpret_cast<float*>(p.out) + pidx * D;
+    if (threadIdx.x == 0) {
+      p.max_logits[pidx] = M;
+      p.exp_sums[pidx] = L;
+    }
+  } else {
+    outp = reinterpret_cast<float*>(p.out) + ((int64_t)seq * p.num_heads + head) * D;
+  }
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float a = 0.f;
+    for (int w = 0; w < NW; ++w) a += o_s[w * D + d] * f[w];
+    outp[d] = a * inv;
+  }
+}
+
+int launch_attn_f32(const AttnParams& p, int kv_dtype, int head_size, int num_seqs, int num_partitions, hipStream_t stream) {
+  switch (head_size) {
+    case 64: case 80: case 96: case 112: case 128: case 192: case 256: break;
+    default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "Unsupported head size: %d", head_size);
+  }
+  const size_t smem = (size_t)(((head_size + 3) & ~3) + 4 * 64 + 8 + 4 * head_size) * sizeof(float);
+  dim3 grid(p.num_heads, num_seqs, num_partitions);
+  switch (kv_dtype) {
+    case NMX_KV_AUTO: paged_attention_f32_kernel<NMX_KV_AUTO><<<grid, 256, smem, stream>>>(p, head_size); break;
+    case NMX_KV_FP8_E4M3: paged_attention_f32_kernel<NMX_KV_FP8_E4M3><<<grid, 256, smem, stream>>>(p, head_size); break;
+    case NMX_KV_FP8_E5M2: paged_attention_f32_kernel<NMX_KV_FP8_E5M2><<<grid, 256, smem, stream>>>(p, head_size); break;
+    default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "Unsupported data type of kv cache: %d", kv_dtype);
+  }
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
 template <typename scalar_t, int KV, int D>
 int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream_t stream) {
   constexpr int NW = 4;
@@ -438,9 +588,9 @@ int run_attention(bool partitioned, void* out, float* exp_sums, float* max_logit
             "Unsupported block size: %d", block_size);
   NMX_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, NMX_ERR_INVALID_ARG,
             "num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
-  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED,
-            "paged_attention: unsupported query dtype code %d (float16 / bfloat16 only on gfx950)", dtype);
-  NMX_CHECK(((uintptr_t)query % 16 == 0) && (q_stride % 8 == 0), NMX_ERR_INVALID_ARG,
+  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16 || dtype == NMX_F32, NMX_ERR_UNSUPPORTED,
+            "paged_attention: unsupported query dtype code %d", dtype);
+  NMX_CHECK(((uintptr_t)query % 16 == 0) && (dtype == NMX_F32 || q_stride % 8 == 0), NMX_ERR_INVALID_ARG,
             "paged_attention: query must be 16-byte aligned with a row stride that is a multiple of 8 elements");
   NMX_CHECK(((uintptr_t)key_cache % 16 == 0) && ((uintptr_t)value_cache % 16 == 0) && kv_block_stride % 16 == 0 &&
                 kv_head_stride % 16 == 0,
@@ -482,13 +632,18 @@ int run_attention(bool partitioned, void* out, float* exp_sums, float* max_logit
   if (partitioned && num_partitions == 0) return NMX_OK;
 
   int rc;
-  if (dtype == NMX_F16) rc = dispatch_kv<f16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
+  if (dtype == NMX_F32) rc = launch_attn_f32(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
+  else if (dtype == NMX_F16) rc = dispatch_kv<f16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
   else rc = dispatch_kv<bf16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
   if (rc != NMX_OK || !partitioned) return rc;
 
   dim3 rgrid(num_heads, num_seqs);
   const size_t rsmem = (size_t)num_partitions * sizeof(float);
-  if (dtype == NMX_F16)
+  if (dtype == NMX_F32)
+    paged_attention_v2_reduce_kernel<float><<<rgrid, 64, rsmem, stream>>>((float*)out, exp_sums, max_logits,
+                                                                          (const float*)tmp_out, seq_lens, num_partitions,
+                                                                          head_size);
+  else if (dtype == NMX_F16)
     paged_attention_v2_reduce_kernel<f16><<<rgrid, 64, rsmem, stream>>>((f16*)out, exp_sums, max_logits, (const f16*)tmp_out,
                                                                         seq_lens, num_partitions, head_size);
   else

@@ -49,7 +49,7 @@ def run_oracle(version, q, kc, vc, kvh, scale, bt, sl, block_size, max_len, alib
     return out
 
 
-@pytest.mark.parametrize("name", ["attn_bf16_gqa", "attn_bf16_alibi_mha"])
+@pytest.mark.parametrize("name", ["attn_bf16_gqa", "attn_bf16_alibi_mha", "attn_f32_gqa"])
 @pytest.mark.parametrize("version", ["v1", "v2"])
 def test_attention_golden(ops, name, version):
     """Outputs of the reference's own CPU backend (bf16; the reference CPU backend has no fp16)."""
@@ -120,6 +120,31 @@ def test_paged_attention_fp8_kv(ops, version, block_size, dtype, kv_dtype):
     out = run_hip(ops, version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
     orc = run_oracle(version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
     torch.testing.assert_close(out.float(), orc.float(), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("head_size", [64, 80, 128, 256])
+@pytest.mark.parametrize("block_size", [8, 16, 32])
+@pytest.mark.parametrize("kv_dtype", ["auto", "fp8"])
+def test_paged_attention_float32(ops, version, head_size, block_size, kv_dtype):
+    """float32 queries (tests/kernels/test_attention.py DTYPES includes torch.float): fp32 cache or fp8 cache,
+    alibi, GQA, ragged lengths across the 512-token partition boundary."""
+    seed_all(5)
+    num_seqs, nq, nkv = 5, 8, 2
+    scale = float(head_size**-0.5)
+    q = torch.empty(num_seqs, nq, head_size, dtype=torch.float32).uniform_(-scale, scale)
+    seq_lens = [1, 511, 513, 1200, 77]
+    max_len = max(seq_lens)
+    mb = (max_len + block_size - 1) // block_size
+    bt = torch.tensor([[random.randint(0, 255) for _ in range(mb)] for _ in range(num_seqs)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(256, block_size, 1, nkv, head_size, kv_dtype, torch.float32)
+    alibi = torch.randn(nq, dtype=torch.float32) * 0.1
+    kv_scale = 0.5 if kv_dtype != "auto" else 1.0
+    out = run_hip(ops, version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, alibi, kv_dtype, kv_scale)
+    orc = run_oracle(version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, alibi, kv_dtype, kv_scale)
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out, orc, atol=1e-3 if kv_dtype == "auto" else 1e-2, rtol=1e-5)
 
 
 @pytest.mark.parametrize("version", ["v1", "v2"])
