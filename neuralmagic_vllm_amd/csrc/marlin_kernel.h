@@ -237,7 +237,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   constexpr int PIECES = (NPIECE + 64 * NG - 1) / (64 * NG);  // per thread
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: K-slice bounds, loop trip counts and load offsets stay in SGPRs
   const int g = lane >> 4;
   const int li = lane & 15;
   const int c8 = li & 7;
@@ -357,13 +357,16 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   // 16-B chunk (ks = cc16 / 4, cc = cc16 % 4), dword e2 -> fragment (ks, g = e2, row), dword cc
   // 2:4: lane group g multiplies quads g and g + 4 of the k-tile (k = 4 g + jj, 16 + 4 g + jj): dword e2 of chunk
   // cc (k = 8 cc + 2 e2 + {0, 1}) -> fragment (ks, g = 2 (cc & 1) + (e2 >> 1), row), dword 2 (cc >> 1) + (e2 & 1)
+  // Rows are stored at position row ^ (2 ks): the 16 pieces of a row (4 ks x 4 cc) would otherwise hit the same 4
+  // banks from 4 lanes each; with the swizzle a ds_write_b32 of 32 lanes touches 32 different banks. The fragment
+  // read permutes its 16 row-lanes the same way (still 16 distinct consecutive 16-byte slots).
   auto store_a = [&](const ARegs& r, char* buf) {
 #pragma unroll
     for (int it = 0; it < PIECES; ++it) {
       const int piece = it * (64 * NG) + ng * 64 + lane;
-      const int row = piece / (SUB * 4);
       const int cc16 = piece % (SUB * 4);
       const int ks = cc16 >> 2, cc = cc16 & 3;
+      const int row = (piece / (SUB * 4)) ^ (2 * ks);
       if (piece < NPIECE) {
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if constexpr ((NMX_ABLATE & 4) != 0) af[mt] = u32x4{(uint32_t)lane, (uint32_t)ksl, (uint32_t)mt, 0x3c003c00u};
-      else af[mt] = *reinterpret_cast<const u32x4*>(abuf + (((ksl * 4 + g) * ROWS + mt * 16 + li) * 16));
+      else af[mt] = *reinterpret_cast<const u32x4*>(abuf + (((ksl * 4 + g) * ROWS + mt * 16 + (li ^ (2 * ksl))) * 16));
     }
 
     if constexpr (SP) {
@@ -618,13 +621,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     auto land_batch = [&](int sub, bool valid, char* buf, auto set_c) {
       constexpr int SET = decltype(set_c)::value;
       const int kbase = sub * (SUB * 32);
+      // rows >= M and k >= K were read as zeros through the buffer descriptor (fast modes: K % (32 SUB) == 0 and
+      // pieces beyond the tile are never stored); only a K slice that has run out of sub-chunks must be blanked
+      if (!valid) {
 #pragma unroll
-      for (int it = 0; it < PIECES; ++it) {
-        const int piece = it * (64 * NG) + ng * 64 + lane;
-        const int row = piece / (SUB * 4);
-        const int cc16 = piece % (SUB * 4);
-        const bool ok = valid && piece < NPIECE && (m0 + row) < M && (kbase + cc16 * 8) < K;
-        areg[SET].v[it] = ok ? areg[SET].v[it] : u32x4{0, 0, 0, 0};
+        for (int it = 0; it < PIECES; ++it) areg[SET].v[it] = u32x4{0, 0, 0, 0};
       }
       if constexpr ((NMX_ABLATE & 256) == 0) store_a(areg[SET], buf);
       if constexpr (ACC_SCALE) {
@@ -719,12 +720,18 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       body(std::integral_constant<int, 0>{}, it);
       if (it + 1 < n_iter) body(std::integral_constant<int, 1>{}, it + 1);
     }
-    // drain: no asm load may still be in flight when its destination registers are reused below
+    // drain: no asm load may still be in flight when its destination registers are reused below. EVERY register an
+    // asm load can still be writing must be an operand of an asm statement placed after the vmcnt(0): the compiler
+    // treats a load's destination as written at the asm statement itself, so the activation / scale registers of the
+    // last (never consumed) prefetch batches are dead to it after the loop - it put epilogue address arithmetic into
+    // them above the drain, and the landing loads then corrupted the K-slice reduction addresses.
     if (n_iter > 0) {
 #pragma unroll
       for (int i = 0; i < PF; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[i].q0), "+v"(ring[i].q1)::"memory");
       }
+      wait_batch(S0{});
+      wait_batch(S1{});
     }
   }
 
