@@ -3,6 +3,7 @@ from typing import Dict, Type
 
 from neuralmagic_vllm_amd.layers.quantization.awq import AWQConfig
 from neuralmagic_vllm_amd.layers.quantization.base_config import QuantizationConfig
+from neuralmagic_vllm_amd.layers.quantization.compressed_tensors import CompressedTensorsConfig
 from neuralmagic_vllm_amd.layers.quantization.fp8 import Fp8Config
 from neuralmagic_vllm_amd.layers.quantization.gptq import GPTQConfig
 from neuralmagic_vllm_amd.layers.quantization.gptq_marlin import GPTQMarlinConfig
@@ -11,6 +12,7 @@ from neuralmagic_vllm_amd.layers.quantization.marlin import MarlinConfig
 
 QUANTIZATION_METHODS: Dict[str, Type[QuantizationConfig]] = {
     "awq": AWQConfig,
+    "compressed-tensors": CompressedTensorsConfig,
     "fp8": Fp8Config,
     "gptq_marlin_24": GPTQMarlin24Config,  # before gptq_marlin / gptq: override order (__init__.py:32-36)
     "gptq": GPTQConfig,

@@ -48,3 +48,33 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
                 assert "liboracle" not in src, f"{f} references liboracle"
+
+
+def test_compressed_tensors_scheme_dispatch():
+    """Host logic only (no GPU): the compressed-tensors config picks the scheme the reference picks
+    (compressed_tensors.py:132-160) and matches targets by class name or regex (utils.py:78-122)."""
+    import torch
+    from neuralmagic_vllm_amd.layers.quantization.compressed_tensors import (
+        CompressedTensorsConfig, CompressedTensorsW4A16Sparse24, CompressedTensorsWNA16, find_first_name_or_class_match)
+    from neuralmagic_vllm_amd.layers.quantization.compressed_tensors_w8a8 import CompressedTensorsW8A8
+
+    class Linear(torch.nn.Module):
+        pass
+
+    def cfg(fmt, w, a=None):
+        return CompressedTensorsConfig.from_config({"format": fmt, "config_groups": {
+            "g": {"targets": ["Linear"], "weights": w, "input_activations": a}}})
+
+    w4 = {"num_bits": 4, "symmetric": True, "strategy": "group", "group_size": 128}
+    assert isinstance(cfg("pack-quantized", w4).get_scheme(Linear()), CompressedTensorsWNA16)
+    assert isinstance(cfg("marlin-24", w4).get_scheme(Linear()), CompressedTensorsW4A16Sparse24)
+    w8 = {"num_bits": 8, "symmetric": True, "strategy": "tensor"}
+    st = cfg("int-quantized", w8, {"num_bits": 8, "symmetric": True, "strategy": "tensor"}).get_scheme(Linear())
+    assert isinstance(st, CompressedTensorsW8A8) and st.is_static_input_scheme
+    with pytest.raises(NotImplementedError):
+        cfg("marlin-24", {"num_bits": 8, "symmetric": True, "strategy": "channel"}).get_scheme(Linear())
+    with pytest.raises(ValueError):
+        CompressedTensorsWNA16("group", 4, None)
+    assert find_first_name_or_class_match("model.layers.0.q_proj", Linear(), ["re:.*q_proj"]) == "re:.*q_proj"
+    assert find_first_name_or_class_match("x", Linear(), ["linear"], check_contains=True) == "linear"
+    assert find_first_name_or_class_match("x", Linear(), ["Conv"]) is None

@@ -198,6 +198,87 @@ def test_int8_w8a8_method():
         assert compute_max_diff(out.cpu(), x.float() @ w.t()) < 0.03
 
 
+def _ct_config(fmt, weights, acts=None):
+    from neuralmagic_vllm_amd.layers.quantization.compressed_tensors import CompressedTensorsConfig
+    return CompressedTensorsConfig.from_config({
+        "format": fmt, "ignore": ["lm_head"],
+        "config_groups": {"group_0": {"targets": ["Linear"], "weights": weights, "input_activations": acts}}})
+
+
+class Linear(torch.nn.Module):  # class name is the compressed-tensors target
+    pass
+
+
+@pytest.mark.parametrize("bits,group", [(4, 128), (8, None)])
+def test_compressed_tensors_wna16(bits, group):
+    """pack-quantized int4/int8 -> CompressedTensorsWNA16 -> gptq_marlin_repack + gptq_marlin_gemm."""
+    from neuralmagic_vllm_amd.layers.quantization.compressed_tensors import CompressedTensorsWNA16
+    seed_all(4)
+    K, N = 256, 256
+    cfg = _ct_config("pack-quantized", {"num_bits": bits, "type": "int", "symmetric": True,
+                                        "strategy": "group" if group else "channel", "group_size": group})
+    method = cfg.get_quant_method(None)
+    layer = Linear()
+    method.create_weights(layer, K, [N], K, N, torch.float16, device=DEV)
+    assert isinstance(layer.scheme, CompressedTensorsWNA16)
+    w = torch.randn(K, N, dtype=torch.float16)
+    gs = group if group else K
+    w_ref, q_w, s, _, _ = packing.quantize_weights(w, bits, gs, False)
+    # checkpoint layout: weight_packed [N, K/pack] (element k of a row in bits (k % pack) * bits), scales [N, K/g]
+    packed = packing.gptq_pack(q_w, bits, K, N).t().contiguous()
+    load(layer, weight_packed=packed.to(DEV), weight_scale=s.t().contiguous().to(DEV))
+    x = torch.randn(2, 7, K, dtype=torch.float16)
+    out = method.apply(layer, x.to(DEV))
+    assert out.shape == (2, 7, N) and compute_max_diff(out.cpu(), x.float() @ w_ref.float()) < 1e-3
+    assert torch.equal(out, method.apply(layer, x.to(DEV)))  # second call: state READY, no repack
+    with pytest.raises(ValueError):
+        method.apply(layer, x.to(DEV), torch.zeros(N, device=DEV))
+
+
+def test_compressed_tensors_w4a16_sparse24():
+    from neuralmagic_vllm_amd.layers.quantization.compressed_tensors import CompressedTensorsW4A16Sparse24
+    seed_all(5)
+    K, N = 256, 256
+    cfg = _ct_config("marlin-24", {"num_bits": 4, "type": "int", "symmetric": True, "strategy": "group", "group_size": 128})
+    method = cfg.get_quant_method(None)
+    layer = Linear()
+    method.create_weights(layer, K, [N], K, N, torch.float16, device=DEV)
+    assert isinstance(layer.scheme, CompressedTensorsW4A16Sparse24)
+    w = torch.randn(K, N, dtype=torch.float16)
+    w_ref, mq, meta, ms = packing.marlin_24_quantize(w, 4, 128)
+    load(layer, weight_packed=mq.to(DEV), meta=meta.to(DEV), scale_packed=ms.to(DEV))
+    x = torch.randn(9, K, dtype=torch.float16)
+    out = method.apply(layer, x.to(DEV))
+    assert compute_max_diff(out.cpu(), x.float() @ w_ref.float()) < 1e-3
+
+
+def test_compressed_tensors_w8a8_via_config():
+    from neuralmagic_vllm_amd.layers.quantization.compressed_tensors_w8a8 import CompressedTensorsW8A8
+    seed_all(6)
+    K, N = 128, 256
+    cfg = _ct_config("int-quantized", {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "channel"},
+                     {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "token", "dynamic": True})
+    method = cfg.get_quant_method(None)
+    layer = Linear()
+    method.create_weights(layer, K, [N], K, N, torch.float16)
+    assert isinstance(layer.scheme, CompressedTensorsW8A8) and not layer.scheme.is_static_input_scheme
+    w = torch.randn(N, K)
+    ws = w.abs().amax(dim=1, keepdim=True) / 127
+    wq = torch.clamp(torch.round(w / ws), -128, 127).to(torch.int8)
+    load(layer, weight=wq, weight_scale=ws)
+    to_dev(layer)
+    method.process_weights_after_loading(layer)
+    x = torch.randn(5, K, dtype=torch.float16)
+    out = method.apply(layer, x.to(DEV))
+    xs = x.float().abs().amax(dim=1, keepdim=True) / 127
+    xq = torch.clamp(torch.round(x.float() / xs), -128, 127)
+    ref = (xq @ wq.float().t()) * xs * ws.t()
+    assert compute_max_diff(out.cpu(), ref) < 2e-3
+    with pytest.raises(NotImplementedError):
+        _ct_config("pack-quantized", {"num_bits": 3, "type": "int", "symmetric": True, "strategy": "channel"}
+                   ).get_scheme(Linear())
+
+
 def test_paged_attention_shim():
     from neuralmagic_vllm_amd.attention.ops.paged_attn import PagedAttention
     seed_all(6)
