@@ -77,6 +77,21 @@ int nmx_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* 
 /* ------------------------------------------------------------------------------------------------------------
  * KV-cache ops. Replace csrc/cache_kernels.cu (schema csrc/torch_bindings.cpp:207-244, csrc/cache.h:8-32).
  * ---------------------------------------------------------------------------------------------------------- */
+/* context_attention_fwd (vllm/attention/ops/prefix_prefill.py:674-812, Triton in the reference): prefill attention of
+ * the new tokens of every sequence over its paged context (k_cache [NB, Hkv, D/x, BS, x] with x = 8, v_cache
+ * [NB, Hkv, D, BS], block table b_loc [batch, bloc_stride]) plus, causally, the new tokens themselves (k, v
+ * [tokens, Hkv, D]). q / out [tokens, H, D]; b_start_loc = first token of each sequence in q, b_seq_len = context +
+ * new tokens, b_ctx_len = context tokens (all int32). Strides in elements (token, head). sliding_window <= 0 = off;
+ * alibi_slopes [H] fp32 or NULL. sm_scale = 1 / sqrt(D) in the reference. float16 / bfloat16. */
+int nmx_context_attention_fwd(void* out, const void* q, const void* k, const void* v, const void* k_cache,
+                              const void* v_cache, const int32_t* b_loc, const int32_t* b_start_loc,
+                              const int32_t* b_seq_len, const int32_t* b_ctx_len, const float* alibi_slopes, int batch,
+                              int num_heads, int num_kv_heads, int head_size, int block_size, int x, int64_t q_stride_t,
+                              int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
+                              int64_t v_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kc_stride_b,
+                              int64_t kc_stride_h, int64_t vc_stride_b, int64_t vc_stride_h, int64_t bloc_stride,
+                              int max_input_len, int sliding_window, float sm_scale, int dtype, nmx_stream_t stream);
+
 /* reshape_and_cache (cache_kernels.cu:253-278). key/value [num_tokens, num_heads, head_size] with row strides in
  * elements; slot_mapping [num_tokens] int64, negative = padding token (skipped). fp8: stores fp8(val / kv_scale). */
 int nmx_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,

@@ -66,6 +66,18 @@ class PagedAttention:
         return output
 
     @staticmethod
+    def forward_prefix(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                       value_cache: torch.Tensor, block_tables: torch.Tensor, query_start_loc: torch.Tensor,
+                       seq_lens_tensor: torch.Tensor, context_lens: torch.Tensor, max_query_len: int,
+                       alibi_slopes: Optional[torch.Tensor], sliding_window: Optional[int]) -> torch.Tensor:
+        """paged_attn.py:183-216 — prefill with a cached prefix (query_start_loc is [batch + 1])."""
+        from neuralmagic_vllm_amd.attention.ops.prefix_prefill import context_attention_fwd
+        output = torch.empty_like(query)
+        context_attention_fwd(query, key, value, output, key_cache, value_cache, block_tables, query_start_loc[:-1],
+                              seq_lens_tensor, context_lens, max_query_len, alibi_slopes, sliding_window)
+        return output
+
+    @staticmethod
     def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor, src_to_dst: torch.Tensor) -> None:
         ops.swap_blocks(src_kv_cache[0], dst_kv_cache[0], src_to_dst)
         ops.swap_blocks(src_kv_cache[1], dst_kv_cache[1], src_to_dst)

@@ -96,6 +96,21 @@ def paged_attention_v2(out, exp_sum, max_logits, tmp_out, query, key_cache, valu
         c_int(blocksparse_vert_stride), c_int(blocksparse_block_size), c_int(blocksparse_head_sliding_step))
 
 
+def context_attention_fwd(q, k, v, o, k_cache, v_cache, b_loc, b_start_loc, b_seq_len, b_ctx_len, max_input_len,
+                          alibi_slopes=None, sliding_window=None) -> None:
+    """vllm/attention/ops/prefix_prefill.py:674-812 (same argument order)."""
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    b_loc_, st_, sl_, cl_ = i32(b_loc), i32(b_start_loc), i32(b_seq_len), i32(b_ctx_len)
+    D = q.shape[-1]
+    lib().orc_context_attention_fwd(
+        _p(o), _p(q), _p(k), _p(v), _p(k_cache), _p(v_cache), _p(b_loc_), _p(st_), _p(sl_), _p(cl_), _p(alibi_slopes),
+        c_int(sl_.shape[0]), c_int(q.shape[1]), c_int(k.shape[1]), c_int(D), c_int(v_cache.shape[3]), c_int(k_cache.shape[4]),
+        c_i64(q.stride(0)), c_i64(q.stride(1)), c_i64(k.stride(0)), c_i64(k.stride(1)), c_i64(v.stride(0)),
+        c_i64(v.stride(1)), c_i64(o.stride(0)), c_i64(o.stride(1)), c_i64(k_cache.stride(0)), c_i64(k_cache.stride(1)),
+        c_i64(v_cache.stride(0)), c_i64(v_cache.stride(1)), c_i64(b_loc_.stride(0)),
+        c_int(sliding_window if sliding_window and sliding_window > 0 else 0), c_f(1.0 / (D**0.5)), c_int(DT[q.dtype]))
+
+
 def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, kv_scale) -> None:
     T, H, D = key.shape
     block_size, x = key_cache.shape[3], key_cache.shape[4]

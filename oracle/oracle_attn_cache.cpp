@@ -301,3 +301,71 @@ void orc_convert_fp8(void* dst, const void* src, int64_t numel, float scale, int
 }
 
 }  // extern "C"
+
+// ---- prefill attention over (paged context + new tokens): vllm/attention/ops/prefix_prefill.py ----------------
+// context_attention_fwd (:674-812; kernels _fwd_kernel :12-247 and _fwd_kernel_alibi :437-672) read as arithmetic:
+// query token i of sequence b sits at position ctx_len + i; it attends to every cached context token (K cache
+// [NB, Hkv, D/x, BS, x], V cache [NB, Hkv, D, BS], located through b_loc) and to the new tokens j <= i (k, v tensors).
+// Logit = sm_scale * q.k; sliding window W > 0: a key at distance >= W gets the logit -10000 (:88-104, :201-204 -
+// NOT -inf, so it still takes part in max / sum exactly as in the reference); alibi: + slope * (key_pos - query_pos)
+// (:552-557, :623-628). Plain softmax in fp32; probabilities are rounded to the value dtype before P.V (:141, :228).
+extern "C" void orc_context_attention_fwd(void* out, const void* q, const void* k, const void* v, const void* k_cache,
+                                          const void* v_cache, const int32_t* b_loc, const int32_t* b_start_loc,
+                                          const int32_t* b_seq_len, const int32_t* b_ctx_len, const float* alibi_slopes,
+                                          int batch, int num_heads, int num_kv_heads, int D, int block_size, int x,
+                                          int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st,
+                                          int64_t v_sh, int64_t o_st, int64_t o_sh, int64_t kc_sb, int64_t kc_sh,
+                                          int64_t vc_sb, int64_t vc_sh, int64_t bloc_stride, int sliding_window,
+                                          float sm_scale, int dt) {
+  const int qpk = num_heads / num_kv_heads;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int b = 0; b < batch; ++b) {
+    for (int h = 0; h < num_heads; ++h) {
+      const int ctx = b_ctx_len[b], q_len = b_seq_len[b] - ctx, start = b_start_loc[b], kvh = h / qpk;
+      const float slope = alibi_slopes ? alibi_slopes[h] : 0.f;
+      std::vector<float> logit((size_t)ctx + q_len), acc(D);
+      for (int i = 0; i < q_len; ++i) {
+        const int qpos = ctx + i, nk = ctx + i + 1;
+        float mx = -INFINITY;
+        for (int j = 0; j < nk; ++j) {
+          float dot = 0.f;
+          if (j < ctx) {
+            const int64_t base = (int64_t)b_loc[b * bloc_stride + j / block_size] * kc_sb + (int64_t)kvh * kc_sh;
+            const int off = j % block_size;
+            for (int d = 0; d < D; ++d)
+              dot += ld(q, (int64_t)(start + i) * q_st + (int64_t)h * q_sh + d, dt) *
+                     ld(k_cache, base + (int64_t)(d / x) * block_size * x + (int64_t)off * x + d % x, dt);
+          } else {
+            const int64_t base = (int64_t)(start + j - ctx) * k_st + (int64_t)kvh * k_sh;
+            for (int d = 0; d < D; ++d)
+              dot += ld(q, (int64_t)(start + i) * q_st + (int64_t)h * q_sh + d, dt) * ld(k, base + d, dt);
+          }
+          float l = dot * sm_scale;
+          if (sliding_window > 0 && qpos - j >= sliding_window) l = -10000.f;
+          if (alibi_slopes) l += slope * (float)(j - qpos);
+          logit[j] = l;
+          mx = std::max(mx, l);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < nk; ++j) {
+          logit[j] = std::exp(logit[j] - mx);
+          sum += logit[j];
+        }
+        std::fill(acc.begin(), acc.end(), 0.f);
+        for (int j = 0; j < nk; ++j) {
+          const float pj = rnd(logit[j] / sum, dt);
+          if (pj == 0.f) continue;
+          if (j < ctx) {
+            const int64_t base = (int64_t)b_loc[b * bloc_stride + j / block_size] * vc_sb + (int64_t)kvh * vc_sh;
+            const int off = j % block_size;
+            for (int d = 0; d < D; ++d) acc[d] += pj * ld(v_cache, base + (int64_t)d * block_size + off, dt);
+          } else {
+            const int64_t base = (int64_t)(start + j - ctx) * v_st + (int64_t)kvh * v_sh;
+            for (int d = 0; d < D; ++d) acc[d] += pj * ld(v, base + d, dt);
+          }
+        }
+        for (int d = 0; d < D; ++d) st(out, (int64_t)(start + i) * o_st + (int64_t)h * o_sh + d, dt, acc[d]);
+      }
+    }
+  }
+}

@@ -197,3 +197,29 @@ def test_half_conversion_matches_torch():
     assert torch.equal(y.view(torch.int16), x.to(torch.float16).view(torch.int16))
     yb = oracle.matmul(x.reshape(-1, 1), w, out_dtype=torch.bfloat16).reshape(-1)
     assert torch.equal(yb.view(torch.int16), x.to(torch.bfloat16).view(torch.int16))
+
+
+@pytest.mark.parametrize("window,use_alibi", [(0, False), (16, False), (0, True)])
+def test_prefix_prefill_oracle_matches_reference_test_expectation(window, use_alibi):
+    """The reference pins context_attention_fwd by comparing with plain causal attention over context + new tokens
+    (tests/kernels/test_prefix_prefill.py:160-215, xformers BlockDiagonalCausalFromBottomRightMask [+ local window]).
+    The oracle (C++ restatement of the Triton kernel's arithmetic) must agree with a torch fp32 statement of that."""
+    import random
+    from util import ref_prefix_prefill, seed_all
+    seed_all(0)
+    batch, H, Hkv, D, BS = 4, 8, 2, 64, 16
+    q_lens = [random.randint(1, 40) for _ in range(batch)]
+    ctx = [0] + [random.randint(1, 50) for _ in range(batch - 1)]
+    T = sum(q_lens)
+    q, k, v = (torch.empty(T, h, D).uniform_(-1, 1) for h in (H, Hkv, Hkv))
+    kc = torch.empty(64, Hkv, D // 8, BS, 8).uniform_(-1, 1)
+    vc = torch.empty(64, Hkv, D, BS).uniform_(-1, 1)
+    b_loc = torch.randperm(64)[:batch * 5].reshape(batch, 5).to(torch.int32)
+    start = torch.cumsum(torch.tensor([0] + q_lens[:-1]), 0).to(torch.int32)
+    sl = torch.tensor([a + b for a, b in zip(q_lens, ctx)], dtype=torch.int32)
+    cl = torch.tensor(ctx, dtype=torch.int32)
+    al = torch.tensor([2.0**-(i + 1) for i in range(H)]) if use_alibi else None
+    o = torch.zeros_like(q)
+    oracle.context_attention_fwd(q, k, v, o, kc, vc, b_loc, start, sl, cl, max(q_lens), al, window)
+    ref = ref_prefix_prefill(q, k, v, kc, vc, b_loc, start, sl, cl, al, window)
+    assert float((o - ref).abs().max()) < 1e-5

@@ -87,3 +87,39 @@ def ref_single_query_cached_kv_attention(query, num_queries_per_kv, key_cache, v
 def compute_max_diff(output: torch.Tensor, output_ref: torch.Tensor) -> float:
     """mean|out - ref| / mean|ref| (reference: utils/marlin_utils.py:208-210)."""
     return float(torch.mean(torch.abs(output.float() - output_ref.float())) / torch.mean(torch.abs(output_ref.float())))
+
+
+def ref_prefix_prefill(q, k, v, k_cache, v_cache, b_loc, b_start_loc, b_seq_len, b_ctx_len, alibi_slopes=None,
+                       sliding_window=0):
+    """fp32 torch restatement of the expected value of the reference's test (tests/kernels/test_prefix_prefill.py:
+    xformers attention with BlockDiagonalCausalFromBottomRightMask [+ local window] over context + new tokens)."""
+    T, H, D = q.shape
+    Hkv = k.shape[1]
+    BS = v_cache.shape[3]
+    out = torch.zeros(T, H, D, dtype=torch.float32)
+    scale = 1.0 / (D**0.5)
+    for b in range(len(b_seq_len)):
+        ctx, n = int(b_ctx_len[b]), int(b_seq_len[b]) - int(b_ctx_len[b])
+        s0 = int(b_start_loc[b])
+        keys = torch.zeros(ctx + n, Hkv, D)
+        vals = torch.zeros(ctx + n, Hkv, D)
+        for j in range(ctx):
+            blk, off = int(b_loc[b, j // BS]), j % BS
+            keys[j] = k_cache[blk, :, :, off, :].reshape(Hkv, D).float()
+            vals[j] = v_cache[blk, :, :, off].float()
+        keys[ctx:] = k[s0:s0 + n].float()
+        vals[ctx:] = v[s0:s0 + n].float()
+        rep = H // Hkv
+        kk = keys.repeat_interleave(rep, dim=1)  # [L, H, D]
+        vv = vals.repeat_interleave(rep, dim=1)
+        logits = torch.einsum("ihd,jhd->hij", q[s0:s0 + n].float(), kk) * scale
+        qpos = torch.arange(ctx, ctx + n)[:, None]
+        kpos = torch.arange(ctx + n)[None, :]
+        mask = kpos > qpos
+        if sliding_window and sliding_window > 0:
+            mask = mask | (qpos - kpos >= sliding_window)
+        if alibi_slopes is not None:
+            logits = logits + alibi_slopes.float()[:, None, None] * (kpos - qpos).float()[None]
+        logits = logits.masked_fill(mask[None], float("-inf"))
+        out[s0:s0 + n] = torch.einsum("hij,jhd->ihd", torch.softmax(logits, dim=-1), vv)
+    return out
