@@ -246,9 +246,17 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   const int kslice = wave / NG;
 
   const int N = p.N, K = p.K, M = p.M;
-  const int n0 = (blockIdx.x * NG + ng) * 64;   // this wave's 64-column group
+  // blockIdx.x enumerates (column tile, row block) so that the row blocks of one column tile are 8 workgroup ids
+  // apart: consecutive ids go to consecutive XCDs, so they land on the SAME XCD a few dispatches apart and the second
+  // row block finds the tile's weights in that XCD's L2 instead of fetching them from HBM again.
+  const int m_blocks = (p.M + ROWS - 1) / ROWS;
+  const int bx_group = blockIdx.x / (8 * m_blocks), bx_r = blockIdx.x % (8 * m_blocks);
+  const int tile_x = bx_group * 8 + (bx_r & 7);
+  const int block_m = bx_r >> 3;
+  if (tile_x * NG * 64 >= p.N) return;      // padding workgroup (column tiles are rounded up to a multiple of 8)
+  const int n0 = (tile_x * NG + ng) * 64;   // this wave's 64-column group
   const bool col_ok = n0 < N;
-  const int m0 = blockIdx.z * ROWS;
+  const int m0 = block_m * ROWS;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_a = smem + (size_t)kslice * 2 * ABUF;  // [2][ABUF] double buffer of this K-slice
@@ -954,7 +962,8 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
   const size_t stage = (size_t)KW * 2 * SUB * 4 * (16 * MT) * 16;
   const size_t red = (KW > 1) ? (size_t)(KW / 2) * NG * MT * 4 * 64 * 4 * sizeof(float) : 0;
   const size_t smem = std::max(stage, red);
-  dim3 grid(ceil_div(p.N, 64 * NG), p.k_splits, ceil_div(p.M, 16 * MT));
+  // x = (column tiles rounded up to the 8 XCDs) x row blocks, see the kernel's blockIdx decoding
+  dim3 grid(ceil_div(ceil_div(p.N, 64 * NG), 8) * 8 * ceil_div(p.M, 16 * MT), p.k_splits, 1);
   auto kern = marlin_gemm_kernel<scalar_t, KIND, MT, NG, MODE, SP, W8>;
   if (smem > 64 * 1024)
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
