@@ -220,6 +220,10 @@ def kernel_breakdown(model, reps=3):
 
 def cpu_baseline(cfg, batch, ctx):
     """Times the CPU oracle (port) on ONE decoder layer's hot-path ops at this batch; scaled to 32 layers."""
+    # threads = the CPU share of this box (affinity mask), capped so that the sample stays a few seconds long
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(ncpu, 32))
+    os.environ["OMP_NUM_THREADS"] = str(threads)  # read when liboracle (OpenMP) is first loaded, below
     import oracle
     from oracle import packing
     torch.manual_seed(0)
@@ -247,8 +251,8 @@ def cpu_baseline(cfg, batch, ctx):
     oracle.paged_attention_v1(out, q, kc, vc, nkv, D**-0.5, bt, sl, BS, ctx, None, "auto", 1.0)
     t_total += time.perf_counter() - t0
     step_s = t_total * cfg["layers"]
-    return dict(value=cpu_batch / step_s, unit="tokens/s", cores=os.cpu_count(), kind="port",
-                sample=f"CPU oracle (dequant + fp32 matmul, scalar attention; OpenMP over {os.cpu_count()} cores) on 1 of "
+    return dict(value=cpu_batch / step_s, unit="tokens/s", cores=threads, kind="port",
+                sample=f"CPU oracle (dequant + fp32 matmul, scalar attention; OpenMP, {threads} threads of {ncpu} visible) on 1 of "
                 f"{cfg['layers']} layers (4 int4 GEMMs + paged attention), batch {cpu_batch} x ctx {ctx}, scaled x{cfg['layers']}; "
                 f"sample took {t_total:.1f} s")
 
@@ -355,11 +359,13 @@ def main():
         if hbm_bound:
             roof = dict(bound="hbm", kernel=dom, achieved=round(d["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(d["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_bytes_per_launch=int(d["bytes"]))
+                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_bytes_per_launch=int(d["bytes"]),
+                        kernels_in_launch=list(d["prof"]))
         else:
             roof = dict(bound="mfma", kernel=dom, achieved=round(d["tflops"], 1), peak=MFMA_F16_PEAK_TF, unit="TFLOP/s",
                         frac=round(d["tflops"] / MFMA_F16_PEAK_TF, 4), traffic=traffic, traffic_source=traffic_src,
-                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_flops_per_launch=float(d["flops"]))
+                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_flops_per_launch=float(d["flops"]),
+                        kernels_in_launch=list(d["prof"]))
         result = {
             "metric": "decode tokens/sec, Llama-3-8B GPTQ-int4 (Marlin-format) TP=1",
             "value": round(value, 1),
