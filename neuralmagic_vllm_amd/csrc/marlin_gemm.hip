@@ -58,7 +58,9 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
 extern "C" int64_t nmx_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k) {
   if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
   const GemmCfg c = pick_cfg(size_m, size_n, size_k);
-  return c.splits > 1 ? (int64_t)c.splits * size_m * size_n * sizeof(float) : 0;
+  int splits = c.splits;
+  if (size_m > 128) splits = std::max(splits, large_splits(size_m, size_n, size_k));
+  return splits > 1 ? (int64_t)splits * size_m * size_n * sizeof(float) : 0;
 }
 
 extern "C" int nmx_gptq_marlin_repack(const int32_t* b_q_weight, const int32_t* perm, int32_t* out, int size_k,

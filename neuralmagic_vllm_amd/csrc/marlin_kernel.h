@@ -845,6 +845,200 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   }
 }
 
+// ---- large-M (prefill) kernel ------------------------------------------------------------------------------------
+// M > 128: the MFMA-bound regime. A 256-row x 256-column tile per 8-wave workgroup; every packed weight is fetched and
+// dequantised ONCE per workgroup (each wave converts the 16-byte Marlin chunk pair it loaded into the four MFMA
+// operand fragments exactly as the decode kernel does and parks them in LDS), then all eight waves (2 row halves x 4
+// column groups, 128 x 64 outputs each = 32 accumulator tiles) read weight and activation fragments from LDS with
+// ds_read_b128: 12 LDS reads per 32 MFMAs, ~2 dequant VALU per MFMA instead of ~4 in the decode kernel's row blocks.
+// Stages of 64 k (two 32-k steps), LDS double-buffered (2 x 64 KiB), global loads of stage s+1 in flight during the
+// MFMAs of stage s. Group scales (group % 64 == 0) are folded into the dequantised fp16 weights like the reference;
+// channel-wise scales are applied to the fp32 accumulators. grid (N / 256 rounded up, k_splits, M / 256 rounded up).
+// NGRP = 64-column groups per workgroup (4: 8 waves, 256 columns, LDS double-buffered, one workgroup per CU;
+// 2: 4 waves, 128 columns, ONE LDS stage of 48 KiB so that two workgroups share a CU and one computes while the other
+// stages - the phases of a barrier-synchronised workgroup otherwise leave the MFMA pipes idle half the time).
+template <typename scalar_t, int KIND, int MODE, int NGRP>
+__global__ __launch_bounds__(128 * NGRP, 2) void marlin_large_kernel(const GemmParams p) {
+  constexpr bool I4 = (KIND == W_INT4);
+  constexpr int BM = 256;
+  constexpr int NTHR = 128 * NGRP;
+  constexpr int APIECES = 2048 / NTHR;         // 16-byte activation pieces per thread and stage
+  constexpr bool DBUF = (NGRP == 4);
+  constexpr int WORDS64 = I4 ? 128 : 256;
+  constexpr int W_IMG = 2 * NGRP * 4 * 64 * 16;  // bytes: [k-step][column group][tile][lane] x 16 B
+  constexpr int A_IMG = 2 * 4 * BM * 16;         // bytes: [k-step][g][row] x 16 B
+  constexpr int STAGE = W_IMG + A_IMG;
+  using bvec_t = typename std::conditional<I4, u32x2, u32x4>::type;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15, c8 = li & 7, hi = li >> 3;
+  const int wm = wave / NGRP, wn = wave % NGRP;   // compute role: rows 128 wm .., column group wn
+  const int lw = wave % NGRP, kw = wave / NGRP;   // load role: column group lw, k-step kw of the stage
+  const int N = p.N, K = p.K, M = p.M;
+  const int nb = blockIdx.x * (64 * NGRP), m0 = blockIdx.z * BM;
+  const int n_load = nb + 64 * lw;
+  const bool load_ok = n_load < N;
+  const int stages_total = K / 64;
+  const int per = (stages_total + p.k_splits - 1) / p.k_splits;
+  const int st_begin = min((int)blockIdx.y * per, stages_total), st_end = min(st_begin + per, stages_total);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t row_words = (int64_t)N * 16 / (I4 ? 8 : 4);
+  const int32_t* bw = p.b + (int64_t)((load_ok ? n_load : 0) / 64) * WORDS64 + (4 * c8 + g) * (I4 ? 4 : 8) + (I4 ? 2 : 4) * hi;
+  const scalar_t* sc = reinterpret_cast<const scalar_t*>(p.scales);
+  const int64_t scale_off = (int64_t)(load_ok ? n_load : 0) + 8 * c8 + 4 * hi;
+  const scalar_t* A = reinterpret_cast<const scalar_t*>(p.a);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bvec_t wq0, wq1;
+  u32x4 areg[APIECES];
+  uint32_t s2[4] = {0, 0, 0, 0};
+  u32x2 sraw = {0, 0};
+  auto load_stage = [&](int st) {
+    const int kstep = st * 2 + kw;
+    wq0 = *reinterpret_cast<const bvec_t*>(bw + (int64_t)(2 * kstep) * row_words);
+    wq1 = *reinterpret_cast<const bvec_t*>(bw + (int64_t)(2 * kstep + 1) * row_words);
+#pragma unroll
+    for (int it = 0; it < APIECES; ++it) {
+      const int piece = it * NTHR + (int)threadIdx.x;
+      const int row = piece >> 3, cc8 = piece & 7;
+      const int m = min(m0 + row, M - 1);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(A + (int64_t)m * K + st * 64 + cc8 * 8);
+      areg[it] = (m0 + row < M) ? v : u32x4{0, 0, 0, 0};
+    }
+    if constexpr (MODE == 1) {
+      // loaded every stage and unpacked in write_stage: a conditional reload would need its data (and so a full
+      // vmcnt(0) drain of this stage's loads) before the MFMAs instead of after them
+      const int grp = min((st * 64) / p.group_size, p.num_groups - 1);
+      sraw = *reinterpret_cast<const u32x2*>(sc + (int64_t)grp * N + scale_off);
+    }
+  };
+  auto write_stage = [&](char* buf) {
+    if constexpr (MODE == 1) {
+      union { u32x2 v; scalar_t e[4]; } raw;
+      raw.v = sraw;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (__is_same(scalar_t, f16)) {
+          union { f16 h[2]; uint32_t u; } pk;
+          pk.h[0] = raw.e[t];
+          pk.h[1] = raw.e[t];
+          s2[t] = pk.u;
+        } else {
+          s2[t] = __builtin_bit_cast(uint32_t, (float)raw.e[t]);
+        }
+      }
+    }
+    // weights: the same chunk -> fragment conversion as the decode kernel (tile x = t: column c8 + 8 t + 32 hi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t w0, w1, d0, d1, d2, d3;
+      if constexpr (I4) {
+        w0 = wq0[t >> 1] >> (8 * (t & 1));
+        w1 = wq1[t >> 1] >> (8 * (t & 1));
+      } else {
+        w0 = wq0[t];
+        w1 = wq1[t];
+      }
+      Dequant<scalar_t, KIND>::run(w0, s2[t], MODE == 1, d0, d1);
+      Dequant<scalar_t, KIND>::run(w1, s2[t], MODE == 1, d2, d3);
+      *reinterpret_cast<u32x4*>(buf + (((kw * NGRP + lw) * 4 + t) * 64 + lane) * 16) = u32x4{d0, d1, d2, d3};
+    }
+    // activations: 16-byte piece (row, k-step ks, chunk cc), dword e2 -> fragment (ks, g = e2, row), dword cc
+    char* ab = buf + W_IMG;
+#pragma unroll
+    for (int it = 0; it < APIECES; ++it) {
+      const int piece = it * NTHR + (int)threadIdx.x;
+      const int cc8 = piece & 7, ks = cc8 >> 2, cc = cc8 & 3;
+      const int row = (piece >> 3) ^ (2 * ks);
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2)
+        *reinterpret_cast<uint32_t*>(ab + ((ks * 4 + e2) * BM + row) * 16 + 4 * cc) = areg[it][e2];
+    }
+  };
+  auto compute_stage = [&](const char* buf) {
+    const char* ab = buf + W_IMG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 wf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const u32x4*>(buf + (((ks * NGRP + wn) * 4 + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(ab + ((ks * 4 + g) * BM + wm * 128 + mt * 16 + (li ^ (2 * ks))) * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mfma_16x16x32<scalar_t>(wf[t], af, acc[mt][t]);
+      }
+    }
+  };
+
+  if (st_begin < st_end) {
+    load_stage(st_begin);
+    write_stage(smem);
+  }
+  __syncthreads();
+  if constexpr (DBUF) {
+    // branch-free body (the last iteration re-stages its own stage into the idle buffer) so that the scheduler can put
+    // the next stage's global loads, dequantisation and LDS writes between this stage's MFMAs
+    for (int st = st_begin; st < st_end; ++st) {
+      const int par = (st - st_begin) & 1;
+      load_stage(min(st + 1, st_end - 1));
+      compute_stage(smem + par * STAGE);
+      write_stage(smem + (par ^ 1) * STAGE);
+      __syncthreads();
+    }
+  } else {
+    // one LDS stage: the next stage's global loads fly during the MFMAs, then [barrier] write [barrier]
+    for (int st = st_begin; st < st_end; ++st) {
+      load_stage(min(st + 1, st_end - 1));
+      compute_stage(smem);
+      __syncthreads();
+      write_stage(smem);
+      __syncthreads();
+    }
+  }
+
+  const int n0 = nb + 64 * wn;
+  if (n0 >= N) return;
+  if constexpr (MODE == 0) {
+    // scale_perm_single: D row 4 g + r of tile t is column 32 (g >> 1) + 8 t + 4 (g & 1) + r of the 64-column group
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 32 * (g >> 1) + 8 * t + 4 * (g & 1) + r;
+        const int cc = col & 7, b = col >> 3;
+        const float sv = Scalar<scalar_t>::to_f32(sc[n0 + 32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3)]);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[mt][t][r] *= sv;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 32 * (g >> 1) + 8 * t + 4 * (g & 1);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + wm * 128 + mt * 16 + li;
+      if (m >= M) continue;
+      if (p.k_splits == 1) {
+        union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = r.u;
+      } else {
+        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * M + m) * N + n) = acc[mt][t];
+      }
+    }
+  }
+}
+
+
 // out[m][n] = cast(sum_s partial[s][m][n]); 4 columns per thread
 template <typename scalar_t>
 __global__ void splitk_reduce_kernel(scalar_t* __restrict__ c, const float* __restrict__ partial, int64_t mn4, int splits) {
@@ -983,8 +1177,62 @@ int launch_mode(const GemmParams& p, const GemmCfg& cfg, hipStream_t stream) {
   return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP>(p, stream);
 }
 
+// K splits of the large-M kernel: enough workgroups for the 256 CUs, stages of 64 k
+inline int large_splits(int M, int N, int K) {
+  const int units = ceil_div(N, 256) * ceil_div(M, 256), stages = K / 64;
+  int sp = 1;
+  while (units * sp < 192 && sp * 2 <= 8 && stages / (sp * 2) >= 8) sp *= 2;
+  return sp;
+}
+inline bool use_large(const GemmParams& p, bool sp24) {
+  if (sp24 || p.M <= 128 || p.perm != nullptr || p.slow_act_order || p.K % 64 != 0 || p.N % 64 != 0) return false;
+  if (p.num_groups > 1 && p.group_size % 64 != 0) return false;
+  if ((int64_t)p.M * p.K * 2 >= (1ll << 31) || (int64_t)p.K * p.N >= (1ll << 31)) return false;
+  if (const char* e = getenv("NMX_GEMM_LARGE")) return atoi(e) != 0;
+  return true;
+}
+
+template <typename scalar_t, int KIND>
+int launch_large(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+  p.k_splits = large_splits(p.M, p.N, p.K);
+  if (p.k_splits > 1) {
+    const int64_t per = (int64_t)p.M * p.N * sizeof(float);
+    const int fit = scratch == nullptr ? 1 : (int)std::min<int64_t>(8, scratch_bytes / per);
+    while (p.k_splits > std::max(1, fit)) p.k_splits /= 2;
+  }
+  p.partial = reinterpret_cast<float*>(scratch);
+  int ngrp = 4;  // measured: 0.75-0.90 PFLOP/s at M = 2048 vs 0.65-0.84 for the two-workgroups-per-CU shape
+  if (const char* e = getenv("NMX_GEMM_LARGE_NGRP")) ngrp = atoi(e) == 2 ? 2 : 4;
+  const size_t smem = (ngrp == 4 ? 2 : 1) * (size_t)(2 * ngrp * 4 * 64 * 16 + 2 * 4 * 256 * 16);
+  dim3 grid(ceil_div(p.N, 64 * ngrp), p.k_splits, ceil_div(p.M, 256));
+#define NMX_LAUNCH_LARGE(MODE_, NGRP_)                                                                              \
+  {                                                                                                                 \
+    auto kern = marlin_large_kernel<scalar_t, KIND, MODE_, NGRP_>;                                                   \
+    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)smem));                                                                        \
+    kern<<<grid, 128 * NGRP_, smem, stream>>>(p);                                                                    \
+  }
+  if (p.num_groups > 1) {
+    if (ngrp == 4) NMX_LAUNCH_LARGE(1, 4) else NMX_LAUNCH_LARGE(1, 2)
+  } else {
+    if (ngrp == 4) NMX_LAUNCH_LARGE(0, 4) else NMX_LAUNCH_LARGE(0, 2)
+  }
+#undef NMX_LAUNCH_LARGE
+  NMX_LAUNCH_CHECK();
+  if (p.k_splits > 1) {
+    const int64_t mn4 = (int64_t)p.M * p.N / 4;
+    splitk_reduce_kernel<scalar_t><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(
+        reinterpret_cast<scalar_t*>(p.c), p.partial, mn4, p.k_splits);
+    NMX_LAUNCH_CHECK();
+  }
+  return NMX_OK;
+}
+
 template <typename scalar_t, int KIND, bool SP = false>
 int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+  if constexpr (!SP) {
+    if (use_large(p, false)) return launch_large<scalar_t, KIND>(p, scratch, scratch_bytes, stream);
+  }
   GemmCfg cfg = pick_cfg(p.M, p.N, p.K);
   p.k_splits = cfg.splits;
   if (p.k_splits > 1) {

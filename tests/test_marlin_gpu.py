@@ -146,6 +146,43 @@ def test_fp8_marlin_gemm(ops, n_chunk, mnk_factors, dtype):
     assert compute_max_diff(out.cpu(), torch.matmul(a.float(), w.float())) < 0.04  # the reference test's own bar
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("num_bits", [4, 8])
+@pytest.mark.parametrize("group_size", [-1, 64, 128])
+@pytest.mark.parametrize("shape", [(129, 256, 512), (300, 320, 1024), (512, 1024, 4096), (1000, 64, 192)])
+def test_marlin_gemm_large_m(ops, dtype, num_bits, group_size, shape):
+    """M > 128 runs the 256 x 256-tile prefill kernel (row / column tiles that are not full, K splits, every mode);
+    (1000, 64, 192) has K % 64 != 0 and must take the row-block path."""
+    size_m, size_n, size_k = shape
+    if group_size > 0 and size_k % group_size:
+        pytest.skip("K not a multiple of the group")
+    seed_all(11)
+    w = torch.randn(size_k, size_n, dtype=dtype)
+    w_ref, mq, ms, _, _, _ = packing.marlin_quantize(w, num_bits, group_size, False)
+    a = torch.randn(size_m, size_k, dtype=dtype)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    out = ops.gptq_marlin_gemm(a.to(DEV), mq.to(DEV), ms.to(DEV), e, e, workspace(size_n), num_bits, size_m, size_n,
+                               size_k, True)
+    ref = a.float() @ w_ref.float()
+    tol = TOL if dtype == torch.float16 else 4e-3  # bf16 output rounding: 2^-9 relative
+    assert compute_max_diff(out.cpu(), ref) < tol
+
+
+def test_fp8_marlin_gemm_large_m(ops):
+    seed_all(12)
+    size_m, size_n, size_k = 384, 512, 1024
+    w = torch.randn(size_k, size_n, dtype=torch.float16)
+    w8 = w.to(torch.float8_e4m3fn)
+    packed = packing.pack_fp8_to_int32(w8)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    mq = ops.gptq_marlin_repack(packed.to(DEV), e, size_k, size_n, 8)
+    scales = packing.marlin_permute_scales(torch.full((1, size_n), 0.5, dtype=torch.float16), size_k, size_n, -1)
+    a = torch.randn(size_m, size_k, dtype=torch.float16)
+    out = ops.fp8_marlin_gemm(a.to(DEV), mq, scales.to(DEV), workspace(size_n), 8, size_m, size_n, size_k)
+    ref = a.float() @ (w8.float() * 0.5)
+    assert compute_max_diff(out.cpu(), ref) < TOL
+
+
 def test_marlin_gemm_errors(ops):
     a = torch.zeros(1, 128, dtype=torch.float16, device=DEV)
     mq = torch.zeros(8, 128, dtype=torch.int32, device=DEV)

@@ -28,7 +28,7 @@ for d in ("/tmp/p2", "/tmp/p3"):
     for r in rows(d, "counter_collection.csv"):
         acc[r["Kernel_Name"][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, c in acc.items():
-        if "marlin" not in k and "reduce" not in k:
+        if "marlin" not in k and "reduce" not in k and "large" not in k:
             continue
         print(k, file=out)
         for name, v in sorted(c.items()):
