@@ -1189,7 +1189,9 @@ inline bool use_large(const GemmParams& p, bool sp24) {
   if (p.num_groups > 1 && p.group_size % 64 != 0) return false;
   if ((int64_t)p.M * p.K * 2 >= (1ll << 31) || (int64_t)p.K * p.N >= (1ll << 31)) return false;
   if (const char* e = getenv("NMX_GEMM_LARGE")) return atoi(e) != 0;
-  return true;
+  // measured (bench.py --sweep): the 256 x 256 tiles win once they alone fill the chip (>= 192 workgroups without K
+  // splits: gate_up from M = 512, qkv at M = 2048); narrower matrices stay on the 64-row row-block path
+  return ceil_div(p.N, 256) * ceil_div(p.M, 256) >= 192;
 }
 
 template <typename scalar_t, int KIND>
