@@ -185,6 +185,38 @@ def test_fp8_marlin_gemm_large_m(ops, monkeypatch):
     assert compute_max_diff(out.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("shape", [(5, 4096, 14336), (64, 4096, 4096), (300, 6144, 4096)])
+@pytest.mark.parametrize("scratch_mb", [0, 1])
+def test_marlin_gemm_without_or_with_small_scratch(shape, scratch_mb):
+    """The C-ABI must stay correct when the caller hands no (or too little) split-K scratch: it degrades to the number
+    of K splits that fit instead of allocating (graph capture) or overrunning the buffer."""
+    import ctypes
+    from neuralmagic_vllm_amd import _lib
+    size_m, size_n, size_k = shape
+    seed_all(21)
+    w = torch.randn(size_k, size_n, dtype=torch.float16) * 0.05
+    w_ref, mq, ms, _, _, _ = packing.marlin_quantize(w, 4, 128, False)
+    a = torch.randn(size_m, size_k, dtype=torch.float16)
+    ag, qg, sg = a.to(DEV), mq.to(DEV), ms.to(DEV)
+    c = torch.empty(size_m, size_n, dtype=torch.float16, device=DEV)
+    ws = workspace(size_n)
+    scratch = torch.empty(scratch_mb << 20, dtype=torch.uint8, device=DEV) if scratch_mb else None
+    guard = None
+    if scratch is not None:  # canary right behind the scratch buffer
+        big = torch.zeros((scratch_mb << 20) + 4096, dtype=torch.uint8, device=DEV)
+        scratch, guard = big[:scratch_mb << 20], big[scratch_mb << 20:]
+        guard.fill_(0x5a)
+    P = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+    rc = _lib.lib().nmx_gptq_marlin_gemm(P(ag), P(qg), P(sg), P(None), P(None), P(c), ctypes.c_int64(ws.numel()), P(scratch),
+                                        ctypes.c_int64(scratch.numel() if scratch is not None else 0), size_m, size_n, size_k,
+                                        4, ms.shape[0], 1, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert compute_max_diff(c.cpu(), a.float() @ w_ref.float()) < TOL
+    if guard is not None:
+        assert bool((guard == 0x5a).all())
+
+
 def test_marlin_gemm_errors(ops):
     a = torch.zeros(1, 128, dtype=torch.float16, device=DEV)
     mq = torch.zeros(8, 128, dtype=torch.int32, device=DEV)
