@@ -101,7 +101,7 @@ __device__ __forceinline__ u32x4 p_to_operand(u32x2 a, u32x2 b) {
 }
 
 template <typename scalar_t, int KV, int D, int NW>
-__global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_kernel(const AttnParams p) {
   constexpr int KS = (D + 31) / 32;  // k-steps of the QK^T product
   constexpr int NT = D / 16;         // 16-wide d tiles of the output
   constexpr int CHUNKS = D / 8;      // 8-element chunks per head vector
@@ -167,12 +167,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const AttnPara
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int n_tiles = (tok_end - tok_begin + kTile - 1) / kTile;
-  for (int tile = wave; tile < n_tiles; tile += NW) {
-    const int t0 = tok_begin + tile * kTile;
-
-    // ---- K fragments: lane (g, i) <- token t0 + 16u + i, chunk 4 ks + g ----
-    u32x4 kf[2][KS];
+  // K fragments of one 32-token tile: lane (g, i) <- token t0 + 16u + i, chunk 4 ks + g; also looks up the physical
+  // block of this lane's V tokens (t0 + 8 g .. + 7)
+  auto load_k = [&](int t0, u32x4 (&kf)[2][KS], int64_t& vphys) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int tok = min(t0 + 16 * u + li, last_tok);
@@ -195,34 +192,49 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const AttnPara
         kf[u][ks] = v;
       }
     }
-
-    // ---- V fragments: lane (g, i) <- row d = 16 nt + i, tokens t0 + 8 g .. + 7 ----
-    u32x4 vf[NT];
-    {
-      const int tokv = t0 + 8 * g;
-      const int tokc = min(tokv, last_tok & ~7);
-      const int64_t phys = bt[tokc >> p.bs_shift];
-      const int off = tokc & bs_mask;
-      const cache_t* vb = vc + phys * p.kv_block_stride + off;
+    vphys = bt[min(t0 + 8 * g, last_tok & ~7) >> p.bs_shift];
+  };
+  // V fragments: lane (g, i) <- row d = 16 nt + i, tokens t0 + 8 g .. + 7
+  auto load_v = [&](int t0, int64_t vphys, u32x4 (&vf)[NT]) {
+    const int tokc = min(t0 + 8 * g, last_tok & ~7);
+    const cache_t* vb = vc + vphys * p.kv_block_stride + (tokc & bs_mask);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int d = 16 * nt + li;
-        if constexpr (!FP8) {
-          vf[nt] = *reinterpret_cast<const u32x4*>(vb + (int64_t)d * BS);
-        } else {
-          const u32x2 w = *reinterpret_cast<const u32x2*>(vb + (int64_t)d * BS);
-          vf[nt] = cvt8_fp8<scalar_t, KV>(w, p.kv_scale);
-        }
+    for (int nt = 0; nt < NT; ++nt) {
+      const int d = 16 * nt + li;
+      if constexpr (!FP8) {
+        vf[nt] = *reinterpret_cast<const u32x4*>(vb + (int64_t)d * BS);
+      } else {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(vb + (int64_t)d * BS);
+        vf[nt] = cvt8_fp8<scalar_t, KV>(w, p.kv_scale);
       }
-      if (t0 + kTile > seq_len) {
-        // zero V for tokens past the end of the sequence: they may hold NaNs (attention_kernels.cu:420-430)
-        const int nvalid = max(0, min(8, seq_len - tokv));
+    }
+  };
+
+  // block-table lookup -> K load -> S = K.Q^T is a chain of two dependent memory round trips per tile; the next
+  // tile's block ids and K fragments are requested before this tile's MFMAs so that it overlaps the compute (a wave
+  // has only 4-8 tiles at decode contexts). V depends on nothing but the block id and is issued at the tile's start.
+  constexpr bool PREFETCH = (D <= 128);  // 32 more registers; the wider heads stay at two waves per SIMD without it
+  const int n_tiles = (tok_end - tok_begin + kTile - 1) / kTile;
+  u32x4 kf[2][KS], kf_n[PREFETCH ? 2 : 1][PREFETCH ? KS : 1];
+  int64_t vphys = 0, vphys_n = 0;
+  if (PREFETCH && wave < n_tiles) load_k(tok_begin + wave * kTile, kf, vphys);
+  for (int tile = wave; tile < n_tiles; tile += NW) {
+    const int t0 = tok_begin + tile * kTile;
+    const bool more = tile + NW < n_tiles;
+    if constexpr (!PREFETCH) load_k(t0, kf, vphys);
+    u32x4 vf[NT];
+    load_v(t0, vphys, vf);
+    if constexpr (PREFETCH) {
+      if (more) load_k(t0 + NW * kTile, kf_n, vphys_n);
+    }
+    if (t0 + kTile > seq_len) {
+      // zero V for tokens past the end of the sequence: they may hold NaNs (attention_kernels.cu:420-430)
+      const int nvalid = max(0, min(8, seq_len - (t0 + 8 * g)));
 #pragma unroll
-        for (int dw = 0; dw < 4; ++dw) {
-          const uint32_t keep = (nvalid >= 2 * dw + 2) ? 0xffffffffu : ((nvalid == 2 * dw + 1) ? 0x0000ffffu : 0u);
+      for (int dw = 0; dw < 4; ++dw) {
+        const uint32_t keep = (nvalid >= 2 * dw + 2) ? 0xffffffffu : ((nvalid == 2 * dw + 1) ? 0x0000ffffu : 0u);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) vf[nt][dw] &= keep;
-        }
+        for (int nt = 0; nt < NT; ++nt) vf[nt][dw] &= keep;
       }
     }
 
@@ -287,6 +299,15 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const AttnPara
     const u32x4 pb = p_to_operand(pk[0], pk[1]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = mfma_16x16x32<scalar_t>(vf[nt], pb, o[nt]);
+    if constexpr (PREFETCH) {
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) kf[u][ks] = kf_n[u][ks];
+        vphys = vphys_n;
+      }
+    }
   }
 
   // ---- combine the NW waves through LDS ----
