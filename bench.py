@@ -230,7 +230,7 @@ def cpu_baseline(cfg, batch, ctx):
     H, I, nh, nkv, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head"]
     shapes = [(H, (nh + 2 * nkv) * D), (nh * D, H), (H, 2 * I), (I, H)]
     t_total = 0.0
-    cpu_batch = min(batch, 8)  # bounded sample: 8 rows of the batch
+    cpu_batch = min(batch, 64)  # bounded sample (a few seconds of wall time on 32 threads)
     for K, N in shapes:
         mq = torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32)
         ms = (torch.rand(K // cfg["group"], N) * 0.01 + 0.005).half()
