@@ -150,12 +150,18 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
       pk[u][1] = pack2<scalar_t>(e[2], e[3]);
     }
     l_part = l_part * alpha + psum;
+    if (__any(alpha != 1.0f)) {  // the running maximum settles after a few tiles: skip the NT x 4 multiplies then
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+    }
     const u32x4 pb = p_to_operand(pk[0], pk[1]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = mfma<scalar_t>(vf[nt], pb, o[nt]);
   };
+
+  // Both phases request the next tile's K fragments (and, for the new tokens, the next V tile) before the MFMAs and
+  // the softmax of the current one: a wave's tile is otherwise two dependent memory round trips (block table -> K,
+  // or V -> LDS -> transposed read) followed by ~16 MFMAs, and the kernel ran at the latency, not the MFMA, rate.
 
   // ---- phase 1: the cached context (no causal mask: every context token precedes every query token) ----
   {
@@ -163,27 +169,32 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
     const scalar_t* kc = reinterpret_cast<const scalar_t*>(p.k_cache) + (int64_t)kvh * p.kc_sh;
     const scalar_t* vc = reinterpret_cast<const scalar_t*>(p.v_cache) + (int64_t)kvh * p.vc_sh;
     const int BS = p.block_size, last = ctx - 1;
-    for (int t0 = 0; t0 < ctx; t0 += 32) {
-      f32x4 s[2];
+    auto load_k = [&](int t0, u32x4 (&kf)[2][KS], int64_t& vphys) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int tok = min(t0 + 16 * u + li, last);
         const scalar_t* kb = kc + (int64_t)bt[tok >> p.bs_shift] * p.kc_sb;
         const int off = tok & (BS - 1);
-        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int chunk = 4 * ks + g;
-          u32x4 kf = {0, 0, 0, 0};
-          if (chunk < CHUNKS) kf = *reinterpret_cast<const u32x4*>(kb + ((int64_t)chunk * BS + off) * 8);
-          s[u] = mfma<scalar_t>(kf, qf[ks], s[u]);
+          u32x4 val = {0, 0, 0, 0};
+          if (chunk < CHUNKS) val = *reinterpret_cast<const u32x4*>(kb + ((int64_t)chunk * BS + off) * 8);
+          kf[u][ks] = val;
         }
       }
+      vphys = bt[min(t0 + 8 * g, last & ~7) >> p.bs_shift];
+    };
+    u32x4 kf[2][KS];
+    int64_t vphys = 0;
+    if (ctx > 0) load_k(0, kf, vphys);
+    for (int t0 = 0; t0 < ctx; t0 += 32) {
+      const bool more = t0 + 32 < ctx;
       u32x4 vf[NT];
       {
         const int tokv = t0 + 8 * g;
         const int tokc = min(tokv, last & ~7);
-        const scalar_t* vb = vc + (int64_t)bt[tokc >> p.bs_shift] * p.vc_sb + (tokc & (BS - 1));
+        const scalar_t* vb = vc + vphys * p.vc_sb + (tokc & (BS - 1));
         const int nvalid = max(0, min(8, ctx - tokv));  // slots past the context may hold anything (NaNs included)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -196,6 +207,14 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
           vf[nt] = val;
         }
       }
+      f32x4 s[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[u] = mfma<scalar_t>(kf[u][ks], qf[ks], s[u]);
+      }
+      if (more) load_k(t0 + 32, kf, vphys);  // into the registers the MFMAs above have just consumed
       softmax_pv(s, t0, ctx, false, vf);
     }
   }
@@ -205,32 +224,47 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
     const scalar_t* Kn = reinterpret_cast<const scalar_t*>(p.k) + (int64_t)kvh * p.k_sh;
     const scalar_t* Vn = reinterpret_cast<const scalar_t*>(p.v) + (int64_t)kvh * p.v_sh;
     const int n_end = min(q_len, r0 + 16);
-    for (int t0 = 0; t0 < n_end; t0 += 32) {
-      // stage V[t0 .. t0+31][0 .. D) row-major (tokens past the sequence as zeros)
-#pragma unroll
-      for (int it = 0; it < (32 * CHUNKS + 63) / 64; ++it) {
-        const int piece = it * 64 + lane;
-        const int tok = piece / CHUNKS, ch = piece % CHUNKS;
-        if (piece < 32 * CHUNKS) {
-          u32x4 val = {0, 0, 0, 0};
-          if (t0 + tok < q_len) val = *reinterpret_cast<const u32x4*>(Vn + (int64_t)(start + t0 + tok) * p.v_st + ch * 8);
-          *reinterpret_cast<u32x4*>(vs + tok * VROW + ch * 16) = val;
-        }
-      }
-      f32x4 s[2];
+    constexpr int VP = (32 * CHUNKS) / 64;  // 16-byte pieces of a V tile per lane
+    auto load_kv = [&](int t0, u32x4 (&kf)[2][KS], u32x4 (&vr)[VP]) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int tok = min(t0 + 16 * u + li, q_len - 1);
         const scalar_t* kb = Kn + (int64_t)(start + tok) * p.k_st;
-        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int chunk = 4 * ks + g;
-          u32x4 kf = {0, 0, 0, 0};
-          if (chunk < CHUNKS) kf = *reinterpret_cast<const u32x4*>(kb + chunk * 8);
-          s[u] = mfma<scalar_t>(kf, qf[ks], s[u]);
+          u32x4 val = {0, 0, 0, 0};
+          if (chunk < CHUNKS) val = *reinterpret_cast<const u32x4*>(kb + chunk * 8);
+          kf[u][ks] = val;
         }
       }
+#pragma unroll
+      for (int it = 0; it < VP; ++it) {
+        const int piece = it * 64 + lane;
+        const int tok = piece / CHUNKS, ch = piece % CHUNKS;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(Vn + (int64_t)(start + min(t0 + tok, q_len - 1)) * p.v_st + ch * 8);
+        vr[it] = (t0 + tok < q_len) ? val : u32x4{0, 0, 0, 0};  // tokens past the sequence as zeros
+      }
+    };
+    u32x4 kf[2][KS];
+    u32x4 vr[VP];
+    if (n_end > 0) load_kv(0, kf, vr);
+    for (int t0 = 0; t0 < n_end; t0 += 32) {
+      const bool more = t0 + 32 < n_end;
+      // stage V[t0 .. t0+31][0 .. D) row-major
+#pragma unroll
+      for (int it = 0; it < VP; ++it) {
+        const int piece = it * 64 + lane;
+        *reinterpret_cast<u32x4*>(vs + (piece / CHUNKS) * VROW + (piece % CHUNKS) * 16) = vr[it];
+      }
+      f32x4 s[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[u] = mfma<scalar_t>(kf[u][ks], qf[ks], s[u]);
+      }
+      if (more) load_kv(t0 + 32, kf, vr);  // into the registers the LDS writes and MFMAs above have just consumed
       __builtin_amdgcn_wave_barrier();  // the tile above is this wave's own; LDS operations of a wave stay in order
       // V^T fragments: lane i of a 16-lane group supplies the address of row (i >> 2), columns 4 (i & 3) .. + 3 of a
       // 4 x 16 block and receives column i of its 4 rows; two blocks = tokens 8g .. 8g + 7 of d column 16 nt + i
