@@ -1,5 +1,5 @@
 // Zero-point int4 formats: AWQ (awq_gemm, awq_dequantize) and GPTQ / exllama (gptq_gemm, gptq_shuffle) for gfx950.
-// Replaces csrc/quantization/awq/gemm_kernels.cu and csrc/quantization/gptq/q_gemm.cu (4-bit paths) of the reference.
+// Replaces csrc/quantization/awq/gemm_kernels.cu and csrc/quantization/gptq/q_gemm.cu (2 / 3 / 4 / 8 bit) of the reference.
 // fp16 only, like the reference (awq.py:43-44, gptq.py).
 //
 // Both formats are consumed as stored (no repack pass); w = (q - z) * s is evaluated in fp16 exactly as the reference
@@ -295,6 +295,108 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(const ZpParams p) {
   }
 }
 
+// ---- GPTQ 2 / 3 / 8-bit (gptq/q_gemm.cu:329-700 gemm kernels, :1386-1470 reconstruct) ------------------------------
+// Legacy bit widths, kept simple: weights stay in the checkpoint's sequential packing (element k of a column is a
+// BITS-wide field of a contiguous bit stream over k: 16 / 4 per word for 2 / 8 bit, 32 per 3 words for 3 bit; qzeros
+// the same along n), gptq_shuffle only applies the act-order row permutation. Every lane extracts the 8 x 4 codes of
+// its MFMA fragment with plain loads (the 4-bit kernel above is the tuned one).
+template <int BITS>
+__device__ __forceinline__ uint32_t gptq_field(const uint32_t* __restrict__ base, int64_t stride, int idx) {
+  // field idx of the bit stream whose words are base[0], base[stride], base[2 stride], ...
+  if constexpr (BITS == 3) {
+    const int pos = 3 * (idx & 31), w = 3 * (idx >> 5) + (pos >> 5), sh = pos & 31;
+    uint32_t v = base[(int64_t)w * stride] >> sh;
+    if (sh > 29) v |= base[(int64_t)(w + 1) * stride] << (32 - sh);
+    return v & 7u;
+  } else {
+    constexpr int PF = 32 / BITS;
+    return (base[(int64_t)(idx / PF) * stride] >> (BITS * (idx % PF))) & ((1u << BITS) - 1u);
+  }
+}
+
+template <int BITS, int MT, bool GATHER, bool PER_ROW_GROUP>
+__global__ __launch_bounds__(256) void gptq_gemm_bits_kernel(const ZpParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int n0 = blockIdx.x * 64;
+  const int nl = n0 + 4 * li;
+  const int m0 = blockIdx.z * 16 * MT;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = p.K / 32;
+  const int workers = p.k_splits * 4;
+  const int per = (steps + workers - 1) / workers;
+  const int s0 = min((blockIdx.y * 4 + wave) * per, steps), s1 = min(s0 + per, steps);
+  const int zwords = p.N * BITS / 32;  // words per qzeros row
+  for (int s = s0; s < s1; ++s) {
+    const int kb = s * 32 + 8 * g;
+    u32x4 af[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = load_a_frag<GATHER>(p, m0 + 16 * mt + li, kb);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = nl + t;
+      union { u32x4 u; f16 h[8]; } w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kb + e;
+        const int grp = PER_ROW_GROUP ? p.g_idx[k] : k / p.G;
+        const int q = (int)gptq_field<BITS>(p.qweight + n, p.N, k);
+        const int z = (int)gptq_field<BITS>(p.qzeros + (int64_t)grp * zwords, 1, n) + 1;  // q_gemm.cu:1408 (zero + 1)
+        w.h[e] = (f16)(float)(q - z) * p.scales[(int64_t)grp * p.N + n];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][t] = mfma_f16(w.u, af[mt], acc[mt][t]);
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  reduce_waves<MT, 4>(acc, smem, wave, lane);
+  if (wave != 0) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * (4 * g + r);
+      if (n >= p.N) continue;
+      if (p.k_splits == 1) {
+        union { f16 h[4]; u32x2 u; } o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o.h[t] = (f16)acc[mt][t][r];
+        *reinterpret_cast<u32x2*>(p.c + (int64_t)m * p.N + n) = o.u;
+      } else {
+        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * p.M + m) * p.N + n) =
+            f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+      }
+    }
+  }
+}
+
+// make_sequential for any bit width (q_gemm.cu:1602-1760): new row k' takes old row q_perm[k']; one thread per
+// (32-row group, column) re-packs BITS words
+template <int BITS>
+__global__ void gptq_make_sequential_bits_kernel(const uint32_t* __restrict__ w, uint32_t* __restrict__ w_new,
+                                                 const int32_t* __restrict__ q_perm, int groups32, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = blockIdx.y;
+  if (n >= N || grp >= groups32) return;
+  uint32_t out[BITS];
+#pragma unroll
+  for (int i = 0; i < BITS; ++i) out[i] = 0;
+  for (int i = 0; i < 32; ++i) {
+    const uint32_t v = gptq_field<BITS>(w + n, N, q_perm[grp * 32 + i]);
+    const int pos = BITS * i;
+    out[pos >> 5] |= v << (pos & 31);
+    if ((pos & 31) + BITS > 32) out[(pos >> 5) + 1] |= v >> (32 - (pos & 31));
+  }
+#pragma unroll
+  for (int i = 0; i < BITS; ++i) w_new[(int64_t)(grp * BITS + i) * N + n] = out[i];
+}
+
 __global__ void zp_reduce_kernel(f16* __restrict__ c, const float* __restrict__ partial, int64_t mn4, int splits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= mn4) return;
@@ -391,7 +493,7 @@ extern "C" int nmx_gptq_gemm(const void* a, const int32_t* qweight, const int32_
                              const int32_t* g_idx, void* c, void* scratch, int64_t scratch_bytes, int m, int n, int k,
                              int groups, int use_exllama, int bit, nmx_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  NMX_CHECK(bit == 4, NMX_ERR_UNSUPPORTED, "gptq_gemm: only 4-bit weights are implemented on gfx950 (got %d)", bit);
+  NMX_CHECK(bit == 2 || bit == 3 || bit == 4 || bit == 8, NMX_ERR_INVALID_ARG, "gptq_gemm: bit must be 2, 3, 4 or 8 (got %d)", bit);
   NMX_CHECK(groups > 0 && k % groups == 0, NMX_ERR_INVALID_ARG, "gptq_gemm: K = %d not divisible by groups = %d", k, groups);
   const int G = k / groups;
   NMX_CHECK(k % 32 == 0 && n % 64 == 0, NMX_ERR_INVALID_ARG, "gptq_gemm: K %% 32 == 0 and N %% 64 == 0 required (K=%d N=%d)", k, n);
@@ -412,6 +514,27 @@ extern "C" int nmx_gptq_gemm(const void* a, const int32_t* qweight, const int32_
     p.k_splits = scratch ? std::max<int>(1, (int)(scratch_bytes / ((int64_t)m * n * 4))) : 1;
   dim3 grid(n_tiles, p.k_splits, m_blocks);
   const size_t smem = (size_t)3 * mt * 4 * 64 * 16;
+  if (bit != 4) {
+    // 2 / 3 / 8 bit: sequential packing for both the exllama and the plain entry (gptq_shuffle only re-orders rows)
+#define NMX_GPTQ_B(B_, MT_, GA, PR) gptq_gemm_bits_kernel<B_, MT_, GA, PR><<<grid, 256, smem, stream>>>(p)
+#define NMX_GPTQ_BITS(B_)                                                                         \
+  do {                                                                                            \
+    if (mt == 1) { if (gather) NMX_GPTQ_B(B_, 1, true, false); else if (per_row) NMX_GPTQ_B(B_, 1, false, true); else NMX_GPTQ_B(B_, 1, false, false); } \
+    else { if (gather) NMX_GPTQ_B(B_, 2, true, false); else if (per_row) NMX_GPTQ_B(B_, 2, false, true); else NMX_GPTQ_B(B_, 2, false, false); }         \
+  } while (0)
+    if (bit == 2) NMX_GPTQ_BITS(2);
+    else if (bit == 3) NMX_GPTQ_BITS(3);
+    else NMX_GPTQ_BITS(8);
+#undef NMX_GPTQ_BITS
+#undef NMX_GPTQ_B
+    NMX_LAUNCH_CHECK();
+    if (p.k_splits > 1) {
+      const int64_t mn4 = (int64_t)m * n / 4;
+      zp_reduce_kernel<<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>((f16*)c, p.partial, mn4, p.k_splits);
+      NMX_LAUNCH_CHECK();
+    }
+    return NMX_OK;
+  }
 #define NMX_GPTQ(MT_, SH, GA, PR) gptq_gemm_kernel<MT_, SH, GA, PR><<<grid, 256, smem, stream>>>(p)
 #define NMX_GPTQ_MT(SH, GA, PR) do { if (mt == 1) NMX_GPTQ(1, SH, GA, PR); else NMX_GPTQ(2, SH, GA, PR); } while (0)
   if (use_exllama) {
@@ -436,7 +559,20 @@ extern "C" int nmx_gptq_gemm(const void* a, const int32_t* qweight, const int32_
 extern "C" int nmx_gptq_shuffle(int32_t* q_weight, int32_t* tmp, const int32_t* q_perm, int size_k, int size_n, int bit,
                                 nmx_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  NMX_CHECK(bit == 4, NMX_ERR_UNSUPPORTED, "gptq_shuffle: only 4-bit weights are implemented on gfx950 (got %d)", bit);
+  NMX_CHECK(bit == 2 || bit == 3 || bit == 4 || bit == 8, NMX_ERR_INVALID_ARG, "gptq_shuffle: bit must be 2, 3, 4 or 8 (got %d)", bit);
+  if (bit != 4) {
+    NMX_CHECK(size_k % 32 == 0, NMX_ERR_INVALID_ARG, "gptq_shuffle: K = %d must be a multiple of 32", size_k);
+    if (q_perm == nullptr || size_k == 0 || size_n == 0) return NMX_OK;  // sequential packing is the kernel's format
+    NMX_CHECK(tmp != nullptr, NMX_ERR_INVALID_ARG, "gptq_shuffle: act-order needs a temporary buffer");
+    const int groups32 = size_k / 32;
+    dim3 grid(ceil_div(size_n, 128), groups32);
+    if (bit == 2) gptq_make_sequential_bits_kernel<2><<<grid, 128, 0, stream>>>((const uint32_t*)q_weight, (uint32_t*)tmp, q_perm, groups32, size_n);
+    else if (bit == 3) gptq_make_sequential_bits_kernel<3><<<grid, 128, 0, stream>>>((const uint32_t*)q_weight, (uint32_t*)tmp, q_perm, groups32, size_n);
+    else gptq_make_sequential_bits_kernel<8><<<grid, 128, 0, stream>>>((const uint32_t*)q_weight, (uint32_t*)tmp, q_perm, groups32, size_n);
+    NMX_LAUNCH_CHECK();
+    NMX_HIP(hipMemcpyAsync(q_weight, tmp, (int64_t)groups32 * bit * size_n * 4, hipMemcpyDeviceToDevice, stream));
+    return NMX_OK;
+  }
   NMX_CHECK(size_k % 8 == 0, NMX_ERR_INVALID_ARG, "gptq_shuffle: K = %d must be a multiple of 8", size_k);
   const int rows8 = size_k / 8;
   const int64_t words = (int64_t)rows8 * size_n;

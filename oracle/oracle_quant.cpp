@@ -214,20 +214,27 @@ void orc_awq_gemm(uint16_t* c, const uint16_t* a, const int32_t* qweight, const 
 
 // gptq dequant (gptq/q_gemm.cu:1387-1417 reconstruct_gptq_kernel): w = half(q - (z + 1)) * s
 // qweight [K/pf, N] (element k at bits (k % pf) * bits of row k / pf), qzeros [groups, N/pf] packed along N,
-// g_idx [K] or null (then group = k / (K / groups)). bits in {2, 4, 8} (3-bit packing is irregular: not covered).
+// g_idx [K] or null (then group = k / (K / groups)). bits in {2, 3, 4, 8}: both tensors are contiguous bit streams of
+// BITS-wide fields (3-bit: 32 fields per 3 words, fields 10 and 21 straddle a word boundary - MatrixView_q3_row,
+// gptq/matrix_view.cuh).
+static inline uint32_t gptq_field(const int32_t* base, int64_t stride, int idx, int bits) {
+  const int64_t pos = (int64_t)bits * idx;
+  const int64_t w = pos >> 5;
+  const int sh = (int)(pos & 31);
+  uint32_t v = (uint32_t)base[w * stride] >> sh;
+  if (sh + bits > 32) v |= (uint32_t)base[(w + 1) * stride] << (32 - sh);
+  return v & ((1u << bits) - 1u);
+}
 void orc_gptq_dequantize(uint16_t* w_out, const int32_t* qweight, const int32_t* qzeros, const uint16_t* scales,
                          const int32_t* g_idx, int K, int N, int groups, int bits) {
-  const int pf = 32 / bits;
-  const uint32_t mask = (1u << bits) - 1;
   const int gs = K / groups;
+  const int64_t zwords = (int64_t)N * bits / 32;
 #pragma omp parallel for
   for (int k = 0; k < K; ++k) {
     const int g = g_idx ? g_idx[k] : k / gs;
     for (int n = 0; n < N; ++n) {
-      const uint32_t qw = (uint32_t)qweight[(int64_t)(k / pf) * N + n];
-      const int q = (qw >> (bits * (k % pf))) & mask;
-      const uint32_t zw = (uint32_t)qzeros[(int64_t)g * (N / pf) + n / pf];
-      const int z = ((zw >> (bits * (n % pf))) & mask) + 1;
+      const int q = (int)gptq_field(qweight + n, N, k, bits);
+      const int z = (int)gptq_field(qzeros + (int64_t)g * zwords, 1, n, bits) + 1;
       const float s = half_to_float(scales[(int64_t)g * N + n]);
       w_out[(int64_t)k * N + n] = float_to_half((float)(q - z) * s);
     }

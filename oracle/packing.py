@@ -47,22 +47,32 @@ def sort_weights(q_w: torch.Tensor, g_idx: torch.Tensor):
     return q_w[sort_indices.long(), :].contiguous(), g_idx[sort_indices.long()].contiguous(), sort_indices
 
 
-# quant_utils.py:125-146: element k sits at bits (k % pf) * bits of row k // pf
+def _pack_stream(v: np.ndarray, num_bits: int, axis: int) -> np.ndarray:
+    """Packs integer codes along `axis` into a contiguous little-endian bit stream of num_bits-wide fields cut into
+    int32 words (2 / 4 / 8 bit: 32 // bits fields per word; 3 bit: 32 fields per 3 words)."""
+    v = np.moveaxis(v.astype(np.uint64), axis, 0)
+    n = v.shape[0]
+    assert (n * num_bits) % 32 == 0
+    words = np.zeros((n * num_bits // 32, ) + v.shape[1:], dtype=np.uint64)
+    for i in range(n):
+        pos = i * num_bits
+        w, sh = pos // 32, pos % 32
+        words[w] |= (v[i] << sh) & 0xffffffff
+        if sh + num_bits > 32:
+            words[w + 1] |= v[i] >> (32 - sh)
+    return np.moveaxis(words.astype(np.uint32).view(np.int32), 0, axis)
+
+
+# quant_utils.py:125-146: element k sits at bits (k % pf) * bits of row k // pf (3 bit: AutoGPTQ's 32-in-3-words stream)
 def gptq_pack(q_w: torch.Tensor, num_bits: int, size_k: int, size_n: int) -> torch.Tensor:
-    pf = 32 // num_bits
-    q = q_w.cpu().numpy().astype(np.uint32).reshape(size_k // pf, pf, size_n)
-    shifts = (np.arange(pf, dtype=np.uint32) * num_bits)[None, :, None]
-    packed = np.bitwise_or.reduce(q << shifts, axis=1)
-    return torch.from_numpy(np.ascontiguousarray(packed.astype(np.int32)))
+    q = q_w.cpu().numpy().reshape(size_k, size_n)
+    return torch.from_numpy(np.ascontiguousarray(_pack_stream(q, num_bits, 0)))
 
 
 def gptq_pack_zeros(z: torch.Tensor, num_bits: int) -> torch.Tensor:
-    """qzeros [groups, N/pf] packed along N; stored value is z - 1 (gptq.py:141-196, q_gemm.cu:1408)."""
-    pf = 32 // num_bits
-    G, N = z.shape
-    zz = ((z.cpu().numpy().astype(np.int64) - 1) & (2**num_bits - 1)).astype(np.uint32).reshape(G, N // pf, pf)
-    shifts = (np.arange(pf, dtype=np.uint32) * num_bits)[None, None, :]
-    return torch.from_numpy(np.ascontiguousarray(np.bitwise_or.reduce(zz << shifts, axis=2).astype(np.int32)))
+    """qzeros [groups, N * bits / 32] packed along N; stored value is z - 1 (gptq.py:141-196, q_gemm.cu:1408)."""
+    zz = (z.cpu().numpy().astype(np.int64) - 1) & (2**num_bits - 1)
+    return torch.from_numpy(np.ascontiguousarray(_pack_stream(zz, num_bits, 1)))
 
 
 # ---- Marlin layout: marlin_perms.py:16-50, marlin_utils.py:25-57 (element map: SURVEY.md appendix A.2) ----

@@ -129,10 +129,61 @@ def oracle_codes(qweight: torch.Tensor) -> torch.Tensor:
     return torch.from_numpy(nib.astype(np.int32))
 
 
-def test_gptq_unsupported_bits(ops):
+@pytest.mark.parametrize("bits", [2, 3, 8])
+@pytest.mark.parametrize("m", [1, 17, 40])
+@pytest.mark.parametrize("k,n,group", [(128, 64, 32), (512, 384, 128), (2048, 1024, 128)])
+@pytest.mark.parametrize("mode", ["exllama", "exllama_act_order", "plain", "plain_act_order"])
+def test_gptq_gemm_other_bits(ops, bits, m, k, n, group, mode):
+    """2 / 3 / 8-bit GPTQ (q_gemm.cu:329-700; 3-bit = 32 codes per 3 words): both entry conventions, act-order through
+    gptq_shuffle's row permutation or through g_idx."""
+    seed_all(4)
+    w = torch.randn(k, n)
+    a = torch.randn(m, k, dtype=torch.float16)
+    w_ref, qweight, qzeros, scales, g_idx = packing.gptq_quantize(w, bits, group)
+    assert qweight.shape == (k * bits // 32, n) and qzeros.shape == (k // group, n * bits // 32)
+    ref = a.float() @ w_ref.float()
+    none = torch.empty(0, device=DEV)
+    if mode == "exllama":
+        qg = qweight.clone().to(DEV)
+        ops.gptq_shuffle(qg, torch.empty(0, dtype=torch.int32, device=DEV), bits)
+        out = ops.gptq_gemm(a.to(DEV), qg, qzeros.to(DEV), scales.to(DEV), none, True, bits)
+    elif mode == "plain":
+        out = ops.gptq_gemm(a.to(DEV), qweight.to(DEV), qzeros.to(DEV), scales.to(DEV), none, False, bits)
+        assert compute_max_diff(out.cpu(), oracle.gptq_gemm(a, qweight, qzeros, scales, None, bits)) < TOL
+    else:
+        perm = torch.randperm(k)
+        codes = torch.from_numpy(_codes(qweight, bits, k))[perm]  # checkpoint rows in arbitrary group order
+        g_idx_ck = g_idx[perm].contiguous()
+        qweight_ck = packing.gptq_pack(codes, bits, k, n)
+        a_ck = a[:, perm].contiguous()
+        if mode == "exllama_act_order":
+            q_perm = torch.argsort(g_idx_ck).to(torch.int32)
+            qg = qweight_ck.to(DEV)
+            ops.gptq_shuffle(qg, q_perm.to(DEV), bits)
+            out = ops.gptq_gemm(a_ck.to(DEV), qg, qzeros.to(DEV), scales.to(DEV), q_perm.to(DEV), True, bits)
+        else:
+            out = ops.gptq_gemm(a_ck.to(DEV), qweight_ck.to(DEV), qzeros.to(DEV), scales.to(DEV), g_idx_ck.to(DEV), False, bits)
+            assert compute_max_diff(out.cpu(), oracle.gptq_gemm(a_ck, qweight_ck, qzeros, scales, g_idx_ck, bits)) < TOL
+    assert compute_max_diff(out.cpu(), ref) < TOL
+
+
+def _codes(qweight: torch.Tensor, bits: int, k: int) -> np.ndarray:
+    """inverse of packing.gptq_pack: [K * bits / 32, N] words -> [K, N] codes (contiguous bit stream along K)."""
+    w = qweight.numpy().view(np.uint32).astype(np.uint64)
+    out = np.zeros((k, w.shape[1]), dtype=np.int32)
+    for i in range(k):
+        pos = i * bits
+        v = w[pos // 32] >> (pos % 32)
+        if pos % 32 + bits > 32:
+            v = v | (w[pos // 32 + 1] << (32 - pos % 32))
+        out[i] = (v & ((1 << bits) - 1)).astype(np.int32)
+    return out
+
+
+def test_gptq_bad_bits(ops):
     a = torch.zeros(1, 128, dtype=torch.float16, device=DEV)
     qw = torch.zeros(128 // 4, 64, dtype=torch.int32, device=DEV)
     z = torch.zeros(1, 16, dtype=torch.int32, device=DEV)
     s = torch.zeros(1, 64, dtype=torch.float16, device=DEV)
-    with pytest.raises(RuntimeError, match="only 4-bit"):
-        ops.gptq_gemm(a, qw, z, s, torch.empty(0, device=DEV), True, 8)
+    with pytest.raises(RuntimeError, match="bit must be 2, 3, 4 or 8"):
+        ops.gptq_gemm(a, qw, z, s, torch.empty(0, device=DEV), True, 5)
