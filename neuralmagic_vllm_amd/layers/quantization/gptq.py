@@ -1,6 +1,7 @@
 """GPTQ (exllama kernels) — mirror of vllm/model_executor/layers/quantization/gptq.py (config :17-80, method :90-231).
-4-bit only on gfx950 for now (2/3/8-bit: SURVEY §8f-4)."""
+2 / 3 / 4 / 8 bit (3-bit: 32 codes per 3 words, pack_factor = 32/3 as in the reference)."""
 import enum
+from fractions import Fraction
 from enum import Enum
 from typing import Any, Dict, List, Optional
 
@@ -19,7 +20,7 @@ class GPTQConfig(QuantizationConfig):
         if self.weight_bits not in [2, 3, 4, 8]:
             raise ValueError("Currently, only 2/3/4/8-bit weight quantization is supported for GPTQ, "
                              f"but got {self.weight_bits} bits.")
-        self.pack_factor = 32 // self.weight_bits
+        self.pack_factor = Fraction(32, self.weight_bits)  # 3-bit: 32/3 codes per word (gptq.py:36)
 
     def __repr__(self) -> str:
         return (f"GPTQConfig(weight_bits={self.weight_bits}, group_size={self.group_size}, desc_act={self.desc_act}),"
@@ -64,7 +65,7 @@ class GPTQLinearMethod(LinearMethodBase):
             raise ValueError("The input size is not aligned with the quantized weight shape. "
                              "This can be caused by too large tensor parallel size.")
         out_pp = sum(output_partition_sizes)
-        if out_pp % cfg.pack_factor != 0:
+        if out_pp % cfg.pack_factor.numerator != 0:
             raise ValueError("The output size is not aligned with the quantized weight shape. "
                              "This can be caused by too large tensor parallel size.")
         group_size = cfg.group_size if cfg.group_size != -1 else input_size

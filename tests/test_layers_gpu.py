@@ -147,6 +147,24 @@ def test_gptq_method(desc_act):
     assert compute_max_diff(out.cpu(), x.float() @ w_ref.float()) < 1e-3
 
 
+@pytest.mark.parametrize("bits", [2, 3, 8])
+def test_gptq_method_other_bits(bits):
+    from neuralmagic_vllm_amd.layers.quantization.gptq import ExllamaState, GPTQConfig
+    seed_all(7)
+    K, N, G = 256, 128, 64
+    method = GPTQConfig.from_config({"bits": bits, "group_size": G, "desc_act": False}).get_quant_method(None)
+    layer = Layer()
+    method.create_weights(layer, K, [N], K, N, torch.float16)
+    assert layer.qweight.shape == (K * bits // 32, N) and layer.qzeros.shape == (K // G, N * bits // 32)
+    w_ref, qweight, qzeros, scales, g_idx = packing.gptq_quantize(torch.randn(K, N), bits, G)
+    load(layer, qweight=qweight, qzeros=qzeros, scales=scales, g_idx=g_idx)
+    layer.to(DEV)
+    x = torch.randn(5, K, dtype=torch.float16)
+    out = method.apply(layer, x.to(DEV))
+    assert layer.exllama_state == ExllamaState.READY
+    assert compute_max_diff(out.cpu(), x.float() @ w_ref.float()) < 1e-3
+
+
 @pytest.mark.parametrize("serialized,scheme", [(False, "dynamic"), (True, "static"), (True, "dynamic")])
 def test_fp8_method(serialized, scheme):
     from neuralmagic_vllm_amd.layers.quantization.fp8 import Fp8Config
