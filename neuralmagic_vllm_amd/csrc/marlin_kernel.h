@@ -1044,8 +1044,21 @@ template <typename scalar_t>
 __global__ void splitk_reduce_kernel(scalar_t* __restrict__ c, const float* __restrict__ partial, int64_t mn4, int splits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= mn4) return;
-  f32x4 acc = *reinterpret_cast<const f32x4*>(partial + i * 4);
-  for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * mn4 + i) * 4);
+  // four slabs in flight per thread (a one-load-per-iteration loop pays a full L2 / MALL round trip per split);
+  // summation order stays s = 0, 1, 2, ... so the result does not depend on the batching
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(s + 0) * mn4 + i) * 4);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(s + 1) * mn4 + i) * 4);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(s + 2) * mn4 + i) * 4);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(s + 3) * mn4 + i) * 4);
+    acc += v0;
+    acc += v1;
+    acc += v2;
+    acc += v3;
+  }
+  for (; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * mn4 + i) * 4);
   union { scalar_t h[4]; u32x2 u; } r;
 #pragma unroll
   for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
