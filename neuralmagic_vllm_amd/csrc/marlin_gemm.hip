@@ -60,6 +60,7 @@ extern "C" int64_t nmx_marlin_gemm_scratch_bytes(int size_m, int size_n, int siz
   const GemmCfg c = pick_cfg(size_m, size_n, size_k);
   int splits = c.splits;
   if (size_m > 128) splits = std::max(splits, large_splits(size_m, size_n, size_k));
+  splits = std::max(splits, pick_decode_cfg(size_m, size_n, size_k).splits);
   return splits > 1 ? (int64_t)splits * size_m * size_n * sizeof(float) : 0;
 }
 

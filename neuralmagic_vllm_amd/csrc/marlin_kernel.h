@@ -179,6 +179,17 @@ struct Dequant<bf16, W_FP8> {
   }
 };
 
+// Lane (g, hi, c8) loaded the four words (sub-tiles j = 0..3) of chunk 4 c8 + g of k-tile 2 ks + hi; it needs words
+// 2 hi, 2 hi + 1 of BOTH k-tiles. Its partner lane ^ 8 (same g and c8, other hi) holds exactly the missing pair and
+// needs the pair this lane does not: one DPP row rotation by 8 per word.
+__device__ __forceinline__ void split_pair(u32x4 r, bool hi, u32x2& q0, u32x2& q1) {
+  const uint32_t s0 = hi ? r[0] : r[2], s1 = hi ? r[1] : r[3];  // what the partner wants
+  const uint32_t t0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0x128, 0xf, 0xf, false);  // row_ror:8
+  const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0x128, 0xf, 0xf, false);
+  q0 = hi ? u32x2{t0, t1} : u32x2{r[0], r[1]};
+  q1 = hi ? u32x2{r[2], r[3]} : u32x2{t0, t1};
+}
+
 struct GemmParams {
   const void* a;           // [M, K]
   const int32_t* b;        // Marlin-packed weight (2:4: compressed non-zeros, Marlin-24 permutation)
@@ -316,7 +327,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   // (2:4: q0 = the k-tile row's words, q1 = the lane's 8 metadata int16: tile x = 2 p + q, k-half cc at 4 p + 2 cc + q)
   using bvec_t = typename std::conditional<I4, u32x2, u32x4>::type;
   using mvec_t = typename std::conditional<SP, u32x4, bvec_t>::type;
-  struct BStep { bvec_t q0; mvec_t q1; };
+  // X4: dense int4, hand-counted loop - ONE 16-byte load per lane and k-step (chunk 4 c8 + g of k-tile 2 ks + hi, all
+  // four words) instead of two 8-byte ones; split_pair() trades the unused half with lane ^ 8. A CU retires about
+  // one vector-memory wave instruction per ~38 cycles whatever its width, so 1 KiB instead of 512 B per instruction
+  // is what lifts the per-CU weight rate.
+  constexpr bool X4 = I4 && !SP && !GENERIC;
+  struct BStep { bvec_t q0; mvec_t q1; u32x4 raw; };
   // metadata: reordered int16 index of (k-tile kt, column n0 + 8 c8 + 2 hi + p + 4 q, k-half cc) is
   // 2 (kt N + n0 + 32 hi + 4 c8) + 4 p + 2 cc + q (format_24.py:21-50 solved for this lane's columns)
   const int64_t meta_off = ((int64_t)(col_ok ? n0 : 0) + 32 * hi + 4 * c8) * 2;  // int16 units
@@ -548,8 +564,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     constexpr int AD = 2;
     constexpr int NSC = (MODE == 1) ? (ACC_SCALE ? 4 : 1) : 0;  // scale loads per batch
     constexpr int BATCH = PIECES + NSC;
-    constexpr int WAIT_B = 2 * PF - 2 + 2 * BATCH;   // weight loads are 2 instructions per k-step
-    constexpr int WAIT_BATCH = AD * 2 * SUB + (AD - 1) * BATCH;
+    constexpr int WI = X4 ? 1 : 2;                    // weight load instructions per k-step
+    constexpr int WAIT_B = WI * (PF - 1) + 2 * BATCH;
+    constexpr int WAIT_BATCH = AD * WI * SUB + (AD - 1) * BATCH;
     static_assert(WAIT_B < 60 && WAIT_BATCH < 60, "vmcnt is 6 bits");
     BStep ring[PF];
     ARegs areg[AD];
@@ -558,6 +575,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     for (int i = 0; i < PF; ++i) {
       ring[i].q0 = bvec_t{};
       ring[i].q1 = mvec_t{};
+      ring[i].raw = u32x4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int d = 0; d < AD; ++d) {
@@ -574,7 +592,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     const i32x4 rs_a = make_rsrc(p.a, (uint32_t)((int64_t)M * K * sizeof(scalar_t)));
     const i32x4 rs_s = make_rsrc(p.scales, (uint32_t)((int64_t)p.num_groups * N * sizeof(scalar_t)));
     const i32x4 rs_m = make_rsrc(SP ? p.meta : p.b, SP ? (uint32_t)((int64_t)ktiles * N * 4) : 0u);
-    const int b_voff = (int)((bw - p.b) * 4);
+    const int b_voff = X4 ? (int)((bw - p.b - 2 * hi) * 4) + hi * row_bytes : (int)((bw - p.b) * 4);
     const int m_voff = (int)(meta_off * 2);
     auto issue_b = [&](int kstep, BStep& r) {
       if constexpr ((NMX_ABLATE & 128) != 0) return;
@@ -584,7 +602,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
         buf_load_x4(r.q1, m_voff, rs_m, kstep * N * 4);
       } else {
         const int soff = 2 * kstep * row_bytes;  // wave-uniform
-        if constexpr (I4) {
+        if constexpr (X4) {
+          buf_load_x4(r.raw, b_voff, rs_b, soff);
+        } else if constexpr (I4) {
           buf_load_x2(r.q0, b_voff, rs_b, soff);
           buf_load_x2(r.q1, b_voff, rs_b, soff + row_bytes);
         } else {
@@ -680,6 +700,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     using S1 = std::integral_constant<int, 1>;
     static_assert(PIECES == 1 || PIECES == 2 || PIECES == 4, "unsupported activation piece count");
     auto wait_b = [&](BStep& r) {
+      if constexpr (X4) {
+        if constexpr ((NMX_ABLATE & 16) == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r.raw) : "n"(WAIT_B) : "memory");
+        if constexpr (std::is_same<bvec_t, u32x2>::value && std::is_same<mvec_t, u32x2>::value) split_pair(r.raw, hi != 0, r.q0, r.q1);
+        return;
+      }
       if constexpr ((NMX_ABLATE & 16) != 0) return;
       asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.q0), "+v"(r.q1) : "n"(WAIT_B) : "memory");
     };
@@ -736,7 +761,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     if (n_iter > 0) {
 #pragma unroll
       for (int i = 0; i < PF; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[i].q0), "+v"(ring[i].q1)::"memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[i].q0), "+v"(ring[i].q1), "+v"(ring[i].raw)::"memory");
       }
       wait_batch(S0{});
       wait_batch(S1{});
@@ -1039,6 +1064,229 @@ __global__ __launch_bounds__(128 * NGRP, 2) void marlin_large_kernel(const GemmP
 }
 
 
+// ---- decode kernel for M <= 32 (int4, K % 128 == 0, channel-wise or group % 128 == 0 scales) -------------------------
+// What the skinny kernel above pays at M <= 32 is not bandwidth but fixed cost: 64-96 workgroups x 4 waves x 8 KiB of
+// weights in flight cannot cover the HBM latency (Little: ~70 KiB per CU are needed), the cure - more workgroups along
+// K - buys a second dependent launch (the split-K reduce, ~5 us) and fp32 partial traffic, and the LDS staging of the
+// activations needs barriers / a second in-order queue. This kernel removes all three for the small-M case:
+//   * one workgroup = NW (8 or 16) waves on ONE 64-column group, each wave a K slice: up to 16 x 16 KiB in flight per
+//     CU without any cross-workgroup split for K = 4096 (gridDim.y K splits remain for long K / tiny N);
+//   * activations never touch LDS: lane (G, row) loads the 16 bytes k = 8 G .. 8 G + 7 of its row for the 32-k step
+//     (one buffer_load_dwordx4 per 16 rows and k-step) and the 4 x 4 (register, lane group) transposition that turns
+//     them into the lane's MFMA fragment {dword g, g + 4, g + 8, g + 12} is two v_permlane32_swap + two
+//     v_permlane16_swap - no barrier anywhere in the main loop;
+//   * every vector-memory op is a compiler-visible buffer intrinsic issued in one fixed order (weights, activations
+//     and scale rows of a 128-k unit two units ahead), so hipcc's counted vmcnt keeps the whole ring in flight;
+//   * group scales are applied to the fp32 group accumulators (16 MT FMAs per 128 k), the K slices are summed through
+//     LDS with one barrier, 256 MT threads each adding NW float4s.
+// grid (N / 64, k_splits, row blocks of 16 MT), block 64 NW. Weight / activation / fragment conventions are those of
+// marlin_gemm_kernel.
+__device__ __forceinline__ u32x4 frag_transpose(u32x4 v) {
+  // (register e, lane group G) -> (register G, lane group e): e = 2 e1 + e0, G = 2 G1 + G0
+  const auto s02 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);  // e1 <-> G1
+  const auto s13 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+  const auto p01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);  // e0 <-> G0
+  const auto p23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+  return u32x4{p01[0], p01[1], p23[0], p23[1]};
+}
+
+template <typename scalar_t, int MT, int NW, bool GROUPED, bool WS>
+__global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_kernel(const GemmParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15, c8 = li & 7, hi = li >> 3;
+  const int N = p.N, K = p.K, M = p.M;
+  const int n0 = blockIdx.x * 64;
+  // row blocks (M > 16 MT) re-read the weights: gridDim.x is a multiple of 8 for every Marlin shape of interest, so
+  // the row blocks of one column group have equal workgroup id % 8 = the same XCD and the later one hits its L2
+  const int m0 = blockIdx.z * (16 * MT);
+
+  // K slice of this wave, in units of 128 k
+  const int total_units = K / 128;
+  const int workers = p.k_splits * NW;
+  const int per = (total_units + workers - 1) / workers;
+  const int worker = blockIdx.y * NW + wave;
+  const int u0 = min(worker * per, total_units), u1 = min(u0 + per, total_units);
+
+  const int row_bytes = N * 8;  // one k-tile row of the packed tensor
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.b), 0, (K / 16) * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, M * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.scales), 0, p.num_groups * N * 2, 0x00020000);
+  // weights: ONE 16-byte load per lane and 32-k step - the whole chunk 4 c8 + g (all four 16-column sub-tiles) of
+  // k-tile 2 ks + hi; the half the lane does not use is traded with lane ^ 8 (which holds the other k-tile) in
+  // split_pair() below. A wave instruction then moves 1 KiB instead of 512 B: the CU's texture-address path retires
+  // roughly one vector-memory wave instruction per ~38 cycles whatever its width (measured: tools/stream_probe.hip,
+  // 16-byte vs 8-byte Marlin pattern), so bytes per instruction is what sets a CU's ingest rate.
+  const int b_voff = ((n0 / 64) * 128 + (4 * c8 + g) * 4) * 4 + hi * row_bytes;
+  int a_voff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + mt * 16 + li;
+    a_voff[mt] = (m < M) ? (m * K + 8 * g) * 2 : 0x7ff00000;  // beyond the descriptor: reads as zero
+  }
+  // group scales. WS = false: applied to the fp32 group accumulators - D row r of tile t is column
+  // 32 (g>>1) + 8 t + 4 (g&1) + r, stored (scale_perm) at position 8 (4 (g&1) + r) + 4 (g>>1) + t -> one 8-byte load
+  // per r (fewest VALU ops, 4 vector-memory instructions per unit). WS = true: folded into the dequantised weights
+  // like the reference does - the lane's four tile columns c8 + 8 t + 32 hi sit at positions 8 c8 + 4 hi + t -> ONE
+  // 8-byte load per unit and no group accumulators (16 more packed multiplies per 32 k; the only form that fits the
+  // 128 registers of the 16-wave shape).
+  constexpr bool WSCALE = GROUPED && WS;
+  constexpr int NS = !GROUPED ? 0 : (WSCALE ? 1 : 4);
+  const int s_voff = WSCALE ? (n0 + 8 * c8 + 4 * hi) * 2 : (n0 + 32 * (g & 1) + 4 * (g >> 1)) * 2;
+
+  struct Unit {
+    u32x4 q[4];
+    u32x4 a[4][MT];
+    u32x2 s[NS > 0 ? NS : 1];
+  };
+  // loads of one 32-k step / of the scale rows of unit u (past the slice: the last unit again, never consumed)
+  auto load_step = [&](int u, int ks, Unit& U) {
+    u = min(u, total_units - 1);
+    U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, (u * 8 + 2 * ks) * row_bytes, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      U.a[ks][mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], (u * 128 + ks * 32) * 2, 0);
+    // pin the issue order: the prologue must queue the loads exactly as the loop does, or the (merged) wait counts
+    // at the loop head degrade to those of the worse of the two orders
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_scales = [&](int u, Unit& U) {
+    if constexpr (GROUPED) {
+      u = min(u, total_units - 1);
+      const int grp = (u * 128) / p.group_size;
+#pragma unroll
+      for (int r = 0; r < NS; ++r) U.s[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff + 16 * r, grp * N * 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto load_unit = [&](int u, Unit& U) {  // same order as compute_unit re-issues them
+    if constexpr (WSCALE) load_scales(u, U);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) load_step(u, ks, U);
+    if constexpr (!WSCALE) load_scales(u, U);
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // consumes unit U and re-issues each of its register sets for unit `next` as soon as it is free
+  auto compute_unit = [&](Unit& U, int next, float keep) {
+    f32x4 gacc[WSCALE ? 1 : MT][4];
+    uint32_t s2[4] = {0, 0, 0, 0};
+    if constexpr (WSCALE) {
+      union { u32x2 v; scalar_t e[4]; } raw;
+      raw.v = U.s[0];
+      load_scales(next, U);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (__is_same(scalar_t, f16)) {
+          union { f16 h[2]; uint32_t u; } pk;
+          pk.h[0] = raw.e[t];
+          pk.h[1] = raw.e[t];
+          s2[t] = keep != 0.f ? pk.u : 0u;
+        } else {
+          s2[t] = __builtin_bit_cast(uint32_t, (float)raw.e[t] * keep);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 af[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = frag_transpose(U.a[ks][mt]);
+      u32x2 q0, q1;  // words 2 hi, 2 hi + 1 of k-tiles 2 ks and 2 ks + 1
+      split_pair(U.q[ks], hi != 0, q0, q1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t w0 = q0[t >> 1] >> (8 * (t & 1)), w1 = q1[t >> 1] >> (8 * (t & 1));
+        uint32_t d0, d1, d2, d3;
+        Dequant<scalar_t, W_INT4>::run(w0, s2[t], WSCALE, d0, d1);
+        Dequant<scalar_t, W_INT4>::run(w1, s2[t], WSCALE, d2, d3);
+        const u32x4 wf = {d0, d1, d2, d3};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if constexpr (WSCALE) acc[mt][t] = mfma_16x16x32<scalar_t>(wf, af[mt], acc[mt][t]);
+          else gacc[mt][t] = mfma_16x16x32<scalar_t>(wf, af[mt], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : gacc[mt][t]);
+        }
+      }
+      load_step(next, ks, U);
+    }
+    if constexpr (WSCALE) {
+    } else if constexpr (GROUPED) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        union { u32x2 v; scalar_t e[4]; } raw;
+        raw.v = U.s[r];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float sv = Scalar<scalar_t>::to_f32(raw.e[t]) * keep;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][t][r] += sv * gacc[mt][t][r];
+        }
+      }
+      load_scales(next, U);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] += gacc[mt][t] * keep;
+    }
+  };
+
+  if (u0 < u1) {
+    Unit ua, ub;
+    load_unit(u0, ua);
+    load_unit(u0 + 1, ub);
+    // always whole pairs, branch-free: an odd last unit computes on the (reloaded) final unit and is dropped through
+    // its weight 0. A conditional second half would make the wait counts at the loop head cover the path that skipped
+    // it (half the ring); a peeled tail costs a third copy of the body and its registers.
+    for (int u = u0; u < u1; u += 2) {
+      compute_unit(ua, u + 2, 1.0f);
+      compute_unit(ub, u + 3, (u + 1 < u1) ? 1.0f : 0.0f);
+    }
+  }
+
+  // ---- sum the NW K slices through LDS: thread e < 256 MT owns float4 e of the workgroup's [MT][4][64] tile image ----
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[(wave * MT * 4 + mt * 4 + t) * 64 + lane] = acc[mt][t];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 256 * MT; e += 64 * NW) {
+    f32x4 sum = red[e];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += red[w * MT * 256 + e];
+    const int mt = e >> 8, t = (e >> 6) & 3, el = e & 63, eg = el >> 4;
+    const int m = m0 + mt * 16 + (el & 15);
+    const int col = 32 * (eg >> 1) + 8 * t + 4 * (eg & 1);  // + r, within the 64-column group
+    if (m >= M) continue;
+    if constexpr (!GROUPED) {
+      // channel-wise scales (every K split scales its own partial); scale_perm_single: position
+      // 32 (b >> 2) + 8 (cc >> 1) + (cc & 1) + 2 (b & 3) holds column cc + 8 b
+      const scalar_t* sc = reinterpret_cast<const scalar_t*>(p.scales) + n0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = col + r, cc = c & 7, b = c >> 3;
+        sum[r] *= Scalar<scalar_t>::to_f32(sc[32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3)]);
+      }
+    }
+    if (p.k_splits == 1) {
+      union { scalar_t h[4]; u32x2 u; } o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o.h[r] = Scalar<scalar_t>::from_f32(sum[r]);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n0 + col) = o.u;
+    } else {
+      *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * M + m) * N + n0 + col) = sum;
+    }
+  }
+}
+
 // out[m][n] = cast(sum_s partial[s][m][n]); 4 columns per thread
 template <typename scalar_t>
 __global__ void splitk_reduce_kernel(scalar_t* __restrict__ c, const float* __restrict__ partial, int64_t mn4, int splits) {
@@ -1157,6 +1405,12 @@ GemmCfg pick_cfg(int M, int N, int K) {
       for (int s = sp + 1; s <= 16; ++s)
         if (friendly(s) && ks(s) >= 8 && units * s >= 256) { if (units * s <= cap) sp = s; break; }
     }
+    if (c.mt == 2) {
+      // 32-row tiles: the fewest splits that give >= 192 workgroups with <= 32 k-steps per wave (qkv at M = 64: 2
+      // splits 16.8 us, 4 splits 18.0; down keeps 8)
+      for (int s = 1; s <= 16; s *= 2)
+        if (friendly(s) && units * s >= 192 && ks(s) <= 32 && ks(s) >= 8 && units * s <= cap) { sp = s; break; }
+    }
   }
   c.splits = sp;
   return c;
@@ -1243,8 +1497,109 @@ int launch_large(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
   return NMX_OK;
 }
 
+// ---- decode kernel dispatch ---------------------------------------------------------------------------------------
+struct DecodeCfg { int mt, nw, splits, ws; };  // nw = 0: not applicable; ws: group scales folded into the weights
+
+// Where marlin_decode_kernel applies and how it is launched. NMX_GEMM_LEAN = "nw,splits[,mt[,ws]]" forces a configuration
+// (nw = 0 disables the kernel) for sweeps.
+inline DecodeCfg pick_decode_cfg(int M, int N, int K) {
+  DecodeCfg c{0, 0, 1, 1};
+  if (M > 64 || K % 128 != 0 || N % 64 != 0) return c;
+  c.mt = M <= 16 ? 1 : 2;
+  const int units = K / 128, groups = N / 64;
+  // Measured (tools/lean_sweep.py, 32-launch graph chains, Llama-3-8B shapes): a CU retires ~one vector-memory wave
+  // instruction per 38 cycles, so what matters is the number of CUs streaming, not the waves per CU - 4-wave
+  // workgroups, K split across workgroups until ~256 of them exist, and the split-K reduce launch is cheaper than
+  // leaving CUs idle. The kernel wins where few column groups exist and the rows fit one tile (activations are read
+  // per wave, so their instruction count grows with M): o / qkv at M <= 16 (7.2 / 8.7 us vs 10.2 / 10.7 at M = 1),
+  // o at M <= 32. Long K (down), wide N (gate_up) and M > 32 stay on marlin_gemm_kernel.
+  const bool wins = K <= 8192 && ((M <= 16 && groups <= 128) || (M <= 32 && groups <= 64));
+  if (wins) {
+    c.nw = 4;
+    while (groups * c.splits * 2 <= 256 && units % (c.nw * c.splits * 2) == 0 && units / (c.nw * c.splits * 2) >= 2)
+      c.splits *= 2;
+  }
+  if (const char* e = getenv("NMX_GEMM_LEAN")) {
+    int nw = 0, sp = 1, mt = 0, ws = 1;
+    const int got = sscanf(e, "%d,%d,%d,%d", &nw, &sp, &mt, &ws);
+    if (got >= 1 && (nw == 0 || nw == 4 || nw == 8 || nw == 16)) {
+      c.nw = nw;
+      c.splits = (got >= 2 && sp >= 1 && sp <= 32) ? sp : 1;
+      if (got >= 3 && (mt == 1 || mt == 2)) c.mt = mt;
+      if (got >= 4) c.ws = ws != 0;
+    }
+  }
+  return c;
+}
+
+template <typename scalar_t, int MT, int NW, bool WS>
+int launch_decode_cfg(const GemmParams& p, hipStream_t stream) {
+  const size_t smem = (size_t)NW * MT * 4096;
+  dim3 grid(p.N / 64, p.k_splits, ceil_div(p.M, 16 * MT));
+#define NMX_LAUNCH_DECODE(GROUPED_)                                                                                  \
+  {                                                                                                                  \
+    auto kern = marlin_decode_kernel<scalar_t, MT, NW, GROUPED_, WS>;                                                    \
+    if (smem > 64 * 1024)                                                                                            \
+      NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  (int)smem));                                                                       \
+    kern<<<grid, 64 * NW, smem, stream>>>(p);                                                                        \
+  }
+  if (p.num_groups > 1) NMX_LAUNCH_DECODE(true) else NMX_LAUNCH_DECODE(false)
+#undef NMX_LAUNCH_DECODE
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+template <typename scalar_t>
+int launch_decode(GemmParams& p, const DecodeCfg& cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+  p.k_splits = cfg.splits;
+  if (p.k_splits > 1) {
+    const int64_t per = (int64_t)p.M * p.N * sizeof(float);
+    const int fit = scratch == nullptr ? 1 : (int)std::min<int64_t>(p.k_splits, scratch_bytes / per);
+    p.k_splits = std::max(1, fit);  // never allocate here: graph capture
+  }
+  p.partial = reinterpret_cast<float*>(scratch);
+  int rc;
+  // the 16-wave shape exists where it fits 128 registers per lane without spilling: 16 rows, fp16
+  constexpr bool HAS16 = __is_same(scalar_t, f16);
+  const bool ws = cfg.ws || p.num_groups == 1;
+  if (cfg.mt == 1) {
+    if (cfg.nw == 16 && HAS16) {
+      if constexpr (HAS16) rc = launch_decode_cfg<scalar_t, 1, 16, true>(p, stream);
+      else rc = NMX_ERR_UNSUPPORTED;
+    } else if (cfg.nw >= 8) {
+      rc = ws ? launch_decode_cfg<scalar_t, 1, 8, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 8, false>(p, stream);
+    } else {
+      rc = ws ? launch_decode_cfg<scalar_t, 1, 4, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 4, false>(p, stream);
+    }
+  } else {
+    if (cfg.nw >= 8)
+      rc = ws ? launch_decode_cfg<scalar_t, 2, 8, true>(p, stream) : launch_decode_cfg<scalar_t, 2, 8, false>(p, stream);
+    else
+      rc = ws ? launch_decode_cfg<scalar_t, 2, 4, true>(p, stream) : launch_decode_cfg<scalar_t, 2, 4, false>(p, stream);
+  }
+  if (rc != NMX_OK) return rc;
+  if (p.k_splits > 1) {
+    const int64_t mn4 = (int64_t)p.M * p.N / 4;
+    splitk_reduce_kernel<scalar_t><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(
+        reinterpret_cast<scalar_t*>(p.c), p.partial, mn4, p.k_splits);
+    NMX_LAUNCH_CHECK();
+  }
+  return NMX_OK;
+}
+
 template <typename scalar_t, int KIND, bool SP = false>
 int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+  if constexpr (!SP && KIND == W_INT4) {
+    // small M, plain int4 (no act-order, channel-wise or 128-multiple groups): the barrier-free decode kernel
+    const bool plain = p.perm == nullptr && !p.slow_act_order && (p.num_groups == 1 || p.group_size % 128 == 0) &&
+                       (int64_t)p.M * p.K * 2 < (1ll << 31) && (int64_t)p.K * p.N < (1ll << 31) &&
+                       (int64_t)p.num_groups * p.N * 2 < (1ll << 31);
+    if (plain) {
+      const DecodeCfg dc = pick_decode_cfg(p.M, p.N, p.K);
+      if (dc.nw != 0) return launch_decode<scalar_t>(p, dc, scratch, scratch_bytes, stream);
+    }
+  }
   if constexpr (!SP) {
     if (use_large(p, false)) return launch_large<scalar_t, KIND>(p, scratch, scratch_bytes, stream);
   }

@@ -1,0 +1,105 @@
+"""Times Marlin int4 GEMM configurations the way the decode step sees them: a chain of 32 launches over 32 distinct
+weight tensors captured in a HIP graph (dependent-launch boundaries included, no profiler), and checks each forced
+configuration against the default path of the skinny kernel on the same inputs.
+
+usage (GPU box): python3 tools/lean_sweep.py [M ...] > gpurun_out/lean_sweep.txt
+cfg strings: "L:nw,splits[,mt]" = marlin_decode_kernel, "S:mt,ng,splits[,w8]" = marlin_gemm_kernel, "S:auto" its heuristic."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from neuralmagic_vllm_amd import _custom_ops as ops  # noqa: E402
+
+SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+NL = 32
+dev = "cuda:0"
+
+
+def set_cfg(cfg):
+    os.environ.pop("NMX_GEMM_CFG", None)
+    os.environ.pop("NMX_GEMM_LEAN", None)
+    kind, val = cfg.split(":")
+    if kind == "L":
+        os.environ["NMX_GEMM_LEAN"] = val
+    else:
+        os.environ["NMX_GEMM_LEAN"] = "0"
+        if val != "auto":
+            os.environ["NMX_GEMM_CFG"] = val
+
+
+def time_graph(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+def cfgs_for(name, M):
+    out = ["S:auto"]
+    if M <= 16:
+        out += ["L:16,1", "L:8,1", "L:8,2", "L:4,2", "L:4,3", "L:4,4", "L:8,1,1,0", "L:4,4,1,0"]
+        if name == "down":
+            out += ["L:8,4", "L:4,8", "L:4,7"]
+    elif M <= 32:
+        out += ["L:8,1", "L:8,2", "L:4,2", "L:4,4", "L:8,1,2,0", "L:4,2,2,0", "S:2,2,2", "S:2,2,4"]
+        if name == "down":
+            out += ["L:4,7", "L:8,4"]
+    else:
+        out += ["L:8,1", "L:8,2", "L:4,2", "L:4,4", "L:4,2,2,0", "S:2,2,2", "S:2,2,4", "S:4,4,2,1"]
+        if name == "down":
+            out += ["L:4,7", "L:8,4", "S:2,2,8"]
+    return out
+
+
+def main():
+    Ms = [int(a) for a in sys.argv[1:]] or [1, 16, 32, 64]
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    e = torch.empty(0, dtype=torch.int32, device=dev)
+    wsp = torch.zeros(28672 // 64 * 16, dtype=torch.int32, device=dev)
+    for name, (K, N) in SHAPES.items():
+        ws = [(torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32, device=dev, generator=g),
+               (torch.rand(K // 128, N, device=dev, generator=g) * 0.004 + 0.002).half()) for _ in range(NL)]
+        for M in Ms:
+            x = torch.randn(M, K, dtype=torch.float16, device=dev)
+            set_cfg("S:auto")
+            ref = ops.gptq_marlin_gemm(x, ws[0][0], ws[0][1], e, e, wsp, 4, M, N, K, True).float()
+            torch.cuda.synchronize()
+            by = K * N // 2 + (K // 128) * N * 2 + 2 * M * K + 2 * M * N
+            for cfg in cfgs_for(name, M):
+                set_cfg(cfg)
+                try:
+                    out = ops.gptq_marlin_gemm(x, ws[0][0], ws[0][1], e, e, wsp, 4, M, N, K, True).float()
+                    torch.cuda.synchronize()
+                    err = ((out - ref).abs().mean() / ref.abs().mean()).item()
+
+                    def run():
+                        for w in ws:
+                            ops.gptq_marlin_gemm(x, w[0], w[1], e, e, wsp, 4, M, N, K, True)
+
+                    us = time_graph(run) / NL
+                    print(f"{name:8} M={M:3d} {cfg:12} {us:7.2f} us  {by / us / 1e3:7.0f} GB/s  relerr_vs_default={err:.2e}", flush=True)
+                except Exception as ex:  # noqa: BLE001
+                    print(f"{name:8} M={M:3d} {cfg:12} FAILED {ex}", flush=True)
+                    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
