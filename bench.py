@@ -271,10 +271,15 @@ def pmc_traffic(kernels, args):
         meta = prof.get("_workload", {"batch": 64, "ctx": 1024})
         if meta.get("batch") != args.batch or meta.get("ctx") != args.ctx:
             return None, None
-        tot = 0.0
-        for k in kernels:
-            tot += prof[k]["fetch_bytes_per_launch_corrected"] + prof[k]["write_bytes_per_launch"]
-        return int(tot), os.path.relpath(files[-1], here)
+        # bytes of all the class's kernels (main kernel(s) + split-K reduce where one ran) per call of the op:
+        # calls = launches of the main kernels
+        present = [k for k in kernels if k in prof]
+        if not present:
+            return None, None
+        tot = sum((prof[k]["fetch_bytes_per_launch_corrected"] + prof[k]["write_bytes_per_launch"]) * prof[k]["launches"]
+                  for k in present)
+        calls = sum(prof[k]["launches"] for k in present if "reduce" not in k)
+        return int(tot / max(calls, 1)), os.path.relpath(files[-1], here)
     except (KeyError, ValueError, OSError):
         return None, None
 
@@ -345,7 +350,7 @@ def main():
         classes = {
             "marlin_gemm_kernel": dict(ms=gem_ms / len(gem), bytes=sum(v["bytes"] for v in gem) / len(gem),
                                        flops=sum(v["flops"] for v in gem) / len(gem), step_ms=gem_ms * gem[0]["launches"],
-                                       prof=("marlin_gemm_kernel", "splitk_reduce_kernel")),
+                                       prof=("marlin_gemm_kernel", "marlin_decode_kernel", "splitk_reduce_kernel")),
             "paged_attention_kernel": dict(ms=att["ms"], bytes=att["bytes"], flops=att["flops"],
                                            step_ms=att["ms"] * att["launches"], prof=("paged_attention_kernel", )),
         }

@@ -412,7 +412,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   // MODE 1 with few row tiles: MFMA on UNSCALED integer-valued weights into per-group accumulators and apply the
   // group scale once per group in fp32 (16 MT FMAs per 128 k instead of 16 packed multiplies per 32 k). This is
   // sum_g s_g * (a . (q - 8)) exactly — slightly MORE accurate than the reference's fp16-rounded (q - 8) * s.
-  constexpr bool ACC_SCALE = (MODE == 1) && (MT <= 2);
+#ifndef NMX_ACC_SCALE_MAX_MT
+#define NMX_ACC_SCALE_MAX_MT 2
+#endif
+  constexpr bool ACC_SCALE = (MODE == 1) && (MT <= NMX_ACC_SCALE_MAX_MT);
   f32x4 gacc[ACC_SCALE ? MT : 1][NTILE];
   float srow[ACC_SCALE ? NTILE : 1][4];
 
@@ -692,13 +695,17 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       else if constexpr (PIECES == 2)
         asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])
                      : "n"(WAIT_BATCH) : "memory");
-      else
+      else if constexpr (PIECES == 4)
         asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(sr[0]),
                      "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]) : "n"(WAIT_BATCH) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%12)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(ar.v[4]),
+                     "+v"(ar.v[5]), "+v"(ar.v[6]), "+v"(ar.v[7]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])
+                     : "n"(WAIT_BATCH) : "memory");
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    static_assert(PIECES == 1 || PIECES == 2 || PIECES == 4, "unsupported activation piece count");
+    static_assert(PIECES == 1 || PIECES == 2 || PIECES == 4 || PIECES == 8, "unsupported activation piece count");
     auto wait_b = [&](BStep& r) {
       if constexpr (X4) {
         if constexpr ((NMX_ABLATE & 16) == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r.raw) : "n"(WAIT_B) : "memory");
@@ -1373,12 +1380,17 @@ GemmCfg pick_cfg(int M, int N, int K) {
   if (M <= 16) { c.mt = 1; c.ng = 1; }
   else if (M <= 32 || (M <= 64 && n64 < 256)) { c.mt = 2; c.ng = 2; }
   else { c.mt = 4; c.ng = 4; c.w8 = 1; }
+  // one 64-row block and >= 256 column groups: 128-column tiles (8 waves = 2 column groups x 4 K slices) fill the chip
+  // without any cross-workgroup K split - no fp32 partials, no reduce launch (gate_up at M = 64: 29.8 us vs 30.5-33.6)
+  if (c.mt == 4 && M <= 64 && n64 >= 448 && K <= 8192) c.ng = 2;
   if (const char* e = getenv("NMX_GEMM_CFG")) {  // tuning override: "mt,ng,splits[,w8]"
     int a = 0, b = 0, s = 0, w = 0;
     const int got = sscanf(e, "%d,%d,%d,%d", &a, &b, &s, &w);
-    if (got >= 3 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && s >= 1 && !(a == 4 && b != 4) && !(a == 2 && b == 1)) {
+    const bool w8 = got == 4 && w != 0 && a == 4;
+    if (got >= 3 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && s >= 1 &&
+        !(a == 4 && b != 4 && !(w8 && b == 2)) && !(a == 2 && b == 1)) {
       c.mt = a; c.ng = b; c.splits = s;
-      c.w8 = (got == 4 && w != 0 && a == 4) ? 1 : 0;
+      c.w8 = w8 ? 1 : 0;
       return c;
     }
   }
@@ -1435,6 +1447,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename scalar_t, int KIND, int MODE, bool SP>
 int launch_mode(const GemmParams& p, const GemmCfg& cfg, hipStream_t stream) {
+  if (cfg.w8 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 4, 2, MODE, SP, true>(p, stream);
   if (cfg.w8) return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP, true>(p, stream);
   if (cfg.mt == 1 && cfg.ng == 1) return launch_cfg<scalar_t, KIND, 1, 1, MODE, SP>(p, stream);
   if (cfg.mt == 1 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 1, 2, MODE, SP>(p, stream);

@@ -3,7 +3,7 @@ weight tensors captured in a HIP graph (dependent-launch boundaries included, no
 configuration against the default path of the skinny kernel on the same inputs.
 
 usage (GPU box): python3 tools/lean_sweep.py [M ...] > gpurun_out/lean_sweep.txt
-cfg strings: "L:nw,splits[,mt]" = marlin_decode_kernel, "S:mt,ng,splits[,w8]" = marlin_gemm_kernel, "S:auto" its heuristic."""
+cfg strings: "L:nw,splits[,mt[,ws]]" = marlin_decode_kernel, "G:ngrp" = marlin_large_kernel, "S:mt,ng,splits[,w8]" = marlin_gemm_kernel, "S:auto" its heuristic."""
 import os
 import sys
 
@@ -18,10 +18,13 @@ dev = "cuda:0"
 
 
 def set_cfg(cfg):
-    os.environ.pop("NMX_GEMM_CFG", None)
-    os.environ.pop("NMX_GEMM_LEAN", None)
+    for k in ("NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP"):
+        os.environ.pop(k, None)
     kind, val = cfg.split(":")
-    if kind == "L":
+    if kind == "G":  # large-M kernel with 64 * val columns per workgroup
+        os.environ["NMX_GEMM_LARGE"] = "1"
+        os.environ["NMX_GEMM_LARGE_NGRP"] = val
+    elif kind == "L":
         os.environ["NMX_GEMM_LEAN"] = val
     else:
         os.environ["NMX_GEMM_LEAN"] = "0"
@@ -53,6 +56,8 @@ def time_graph(fn, reps=5):
 
 def cfgs_for(name, M):
     out = ["S:auto"]
+    if M > 64:
+        return out + ["G:2", "G:4", "S:4,4,1,1", "S:4,4,2,1", "S:4,2,1,1"]
     if M <= 16:
         out += ["L:16,1", "L:8,1", "L:8,2", "L:4,2", "L:4,3", "L:4,4", "L:8,1,1,0", "L:4,4,1,0"]
         if name == "down":
@@ -62,7 +67,7 @@ def cfgs_for(name, M):
         if name == "down":
             out += ["L:4,7", "L:8,4"]
     else:
-        out += ["L:8,1", "L:8,2", "L:4,2", "L:4,4", "L:4,2,2,0", "S:2,2,2", "S:2,2,4", "S:4,4,2,1"]
+        out += ["S:2,2,2", "S:2,2,4", "S:4,4,2,1", "S:4,2,1,1", "S:4,2,2,1", "S:4,2,4,1"]
         if name == "down":
             out += ["L:4,7", "L:8,4", "S:2,2,8"]
     return out
@@ -83,7 +88,8 @@ def main():
             ref = ops.gptq_marlin_gemm(x, ws[0][0], ws[0][1], e, e, wsp, 4, M, N, K, True).float()
             torch.cuda.synchronize()
             by = K * N // 2 + (K // 128) * N * 2 + 2 * M * K + 2 * M * N
-            for cfg in cfgs_for(name, M):
+            only = os.environ.get("LEAN_SWEEP_ONLY")
+            for cfg in (only.split(";") if only else cfgs_for(name, M)):
                 set_cfg(cfg)
                 try:
                     out = ops.gptq_marlin_gemm(x, ws[0][0], ws[0][1], e, e, wsp, 4, M, N, K, True).float()
