@@ -29,6 +29,27 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16
 
 LLAMA3_8B = dict(hidden=4096, inter=14336, heads=32, kv_heads=8, head=128, layers=32, vocab=128256, group=128)
+# one TP=8 rank of Llama-3-70B (8 q heads + 1 kv head, inter 28672 / 8 per rank, 80 layers)
+LLAMA3_70B_TP8_RANK = dict(hidden=8192, inter=3584, heads=8, kv_heads=1, head=128, layers=80, vocab=128256 // 8, group=128)
+
+# BASELINE.json configs[1..4]. "int4" is the headline (the metric is quoted on it); the others are selected with
+# --config and print the same JSON line for their own workload.
+VARIANTS = {
+    "int4": dict(model=LLAMA3_8B, kv="auto",
+                 metric="decode tokens/sec, Llama-3-8B GPTQ-int4 (Marlin-format) TP=1",
+                 workload="Llama-3-8B GPTQ-int4 g128 decode step, TP=1 (configs[1])"),
+    "sparse24": dict(model=LLAMA3_8B, kv="auto",
+                     metric="decode tokens/sec, Llama-3-8B 2:4-sparse + int4 (sparse-Marlin) TP=1",
+                     workload="Llama-3-8B 2:4-sparse int4 g128 decode step (gptq_marlin_24_gemm), TP=1 (configs[2])"),
+    "fp8": dict(model=LLAMA3_8B, kv="fp8",
+                metric="decode tokens/sec, Llama-3-8B fp8 weights + fp8 KV TP=1",
+                workload="Llama-3-8B fp8 W8A8 (dynamic per-tensor activation quant + scaled_mm) + fp8-e4m3 KV decode step, "
+                         "TP=1 (configs[3])"),
+    "awq70b-tp8rank": dict(model=LLAMA3_70B_TP8_RANK, kv="auto",
+                           metric="decode tokens/sec of ONE TP=8 rank, Llama-3-70B AWQ-int4 (no all-reduce in the timed step)",
+                           workload="Llama-3-70B AWQ-int4 g128, the per-rank shard of TP=8 (configs[4]): compute of one rank, "
+                                    "the 2 all-reduces per layer are not part of this single-GPU line"),
+}
 
 
 def parse():
@@ -38,7 +59,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="sequences decoded per step and per GPU")
     ap.add_argument("--ctx", type=int, default=1024, help="KV context length of every sequence")
-    ap.add_argument("--layers", type=int, default=LLAMA3_8B["layers"])
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(VARIANTS), default="int4", help="which BASELINE.json config to run")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
@@ -53,12 +75,36 @@ def random_marlin_weight(K, N, group, device, gen):
     return q, s
 
 
+def random_weight(variant, K, N, group, device, gen):
+    """Random-init weights of one linear layer in the layout the variant's op consumes."""
+    if variant == "int4":
+        return random_marlin_weight(K, N, group, device, gen)
+    s = (torch.rand(K // group, N, device=device, generator=gen) * 0.004 + 0.002).to(torch.float16)
+    if variant == "sparse24":
+        # compressed non-zeros [K/2/16, N*16/8] + 2-bit positions [K/32, 2N] int16: every quad keeps elements 0 and 1
+        # (nibble 0b0100) - a valid encoding; which positions are kept does not change the work
+        q = torch.randint(-2**31, 2**31 - 1, (K // 32, N * 2), dtype=torch.int32, device=device, generator=gen)
+        meta = torch.full((K // 32, N * 2), 0x4444, dtype=torch.int16, device=device)
+        return q, meta, s
+    if variant == "fp8":
+        # [N, K] row-major fp8 weight, used as its column-major [K, N] transpose view (fp8.py:349-359)
+        w = (torch.randn(N, K, device=device, generator=gen, dtype=torch.float16) * 0.02).to(torch.float8_e4m3fn)
+        return w.t(), torch.full((1, ), 0.01, dtype=torch.float32, device=device)
+    if variant == "awq70b-tp8rank":
+        q = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int32, device=device, generator=gen)
+        z = torch.randint(-2**31, 2**31 - 1, (K // group, N // 8), dtype=torch.int32, device=device, generator=gen)
+        return q, z, s
+    raise ValueError(variant)
+
+
 class Llama3Decode:
     """Synthetic Llama-3-8B decode step driver (the *caller* of the hot path; stands in for vllm's LlamaForCausalLM)."""
 
-    def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16):
+    def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16, variant="int4"):
         self.ops, self.cfg, self.B, self.L, self.dev = ops, cfg, batch, ctx, device
         self.n_layers = n_layers
+        self.variant = variant
+        self.kv_dtype = VARIANTS[variant]["kv"]
         H, I, nh, nkv, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head"]
         self.q_size, self.kv_size = nh * D, nkv * D
         g = torch.Generator(device=device)
@@ -68,7 +114,7 @@ class Llama3Decode:
         for _ in range(n_layers):
             lw = {}
             for name, (K, N) in self.shapes.items():
-                lw[name] = random_marlin_weight(K, N, cfg["group"], device, g)
+                lw[name] = random_weight(variant, K, N, cfg["group"], device, g)
             lw["ln1"] = torch.ones(H, dtype=torch.float16, device=device)
             lw["ln2"] = torch.ones(H, dtype=torch.float16, device=device)
             self.layers.append(lw)
@@ -82,9 +128,15 @@ class Llama3Decode:
         scale = D**-0.5
         self.kv = []
         for _ in range(n_layers):
-            kc = torch.empty(NB, nkv, D // 8, block_size, 8, dtype=torch.float16, device=device).uniform_(-scale, scale, generator=g)
-            vc = torch.empty(NB, nkv, D, block_size, dtype=torch.float16, device=device).uniform_(-scale, scale, generator=g)
+            if self.kv_dtype == "fp8":
+                # fp8 caches are uint8 tensors with x = 16 (vllm/utils.py:471-472); bytes below 0x78 are finite e4m3 values
+                kc = torch.randint(0, 0x78, (NB, nkv, D // 16, block_size, 16), dtype=torch.uint8, device=device, generator=g)
+                vc = torch.randint(0, 0x78, (NB, nkv, D, block_size), dtype=torch.uint8, device=device, generator=g)
+            else:
+                kc = torch.empty(NB, nkv, D // 8, block_size, 8, dtype=torch.float16, device=device).uniform_(-scale, scale, generator=g)
+                vc = torch.empty(NB, nkv, D, block_size, dtype=torch.float16, device=device).uniform_(-scale, scale, generator=g)
             self.kv.append((kc, vc))
+        self.kv_scale = 0.05 if self.kv_dtype == "fp8" else 1.0
         self.block_tables = torch.randperm(NB, generator=g, device=device).to(torch.int32).reshape(batch, blocks_per_seq)
         self.seq_lens = torch.full((batch, ), ctx, dtype=torch.int32, device=device)
         last = ctx - 1  # the new token is written at position ctx-1 and attended with the ctx-1 cached ones
@@ -94,7 +146,8 @@ class Llama3Decode:
         ang = torch.arange(ctx, device=device).float()[:, None] * inv_freq[None, :]
         self.cos_sin_cache = torch.cat((ang.cos(), ang.sin()), dim=-1).half()  # [max_pos, rot_dim] (rotary_embedding.py)
         self.tokens = torch.randint(0, cfg["vocab"], (batch, ), generator=g, device=device)
-        self.workspace = torch.zeros(max(N for _, N in self.shapes.values()) // 64 * 16, dtype=torch.int32, device=device)
+        # gptq_marlin: (N / 64) * 16 ints, gptq_marlin_24: (N / 128) * 64
+        self.workspace = torch.zeros(max(N for _, N in self.shapes.values()) // 64 * 32, dtype=torch.int32, device=device)
         self.empty = torch.empty(0, dtype=torch.int32, device=device)
         self.scale = float(scale)
         # v2 temporaries (vllm/attention/ops/paged_attn.py:148-158)
@@ -108,7 +161,17 @@ class Llama3Decode:
 
     def gemm(self, x, w, name):
         K, N = self.shapes[name]
-        return self.ops.gptq_marlin_gemm(x, w[0], w[1], self.empty, self.empty, self.workspace, 4, x.shape[0], N, K, True)
+        ops = self.ops
+        if self.variant == "int4":
+            return ops.gptq_marlin_gemm(x, w[0], w[1], self.empty, self.empty, self.workspace, 4, x.shape[0], N, K, True)
+        if self.variant == "sparse24":
+            return ops.gptq_marlin_24_gemm(x, w[0], w[1], w[2], self.workspace, 4, x.shape[0], N, K)
+        if self.variant == "fp8":
+            # Fp8LinearMethod.apply (fp8.py:340-359): dynamic per-tensor activation scale, then the scaled matmul
+            qx, sx = ops.scaled_fp8_quant(x)
+            return ops.cutlass_scaled_mm(qx, w[0], sx, w[1], torch.float16)
+        # AWQLinearMethod.apply (awq.py:166-172)
+        return ops.awq_gemm(x, w[0], w[2], w[1], 8)
 
     def attention(self, q, layer):
         cfg = self.cfg
@@ -116,10 +179,11 @@ class Llama3Decode:
         out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
         if self.use_v1:
             self.ops.paged_attention_v1(out, q, kc, vc, cfg["kv_heads"], self.scale, self.block_tables, self.seq_lens,
-                                        self.BS, self.L, None, "auto", 1.0)
+                                        self.BS, self.L, None, self.kv_dtype, self.kv_scale)
         else:
             self.ops.paged_attention_v2(out, self.exp_sums, self.max_logits, self.tmp_out, q, kc, vc, cfg["kv_heads"],
-                                        self.scale, self.block_tables, self.seq_lens, self.BS, self.L, None, "auto", 1.0)
+                                        self.scale, self.block_tables, self.seq_lens, self.BS, self.L, None, self.kv_dtype,
+                                        self.kv_scale)
         return out
 
     def step(self):
@@ -142,7 +206,8 @@ class Llama3Decode:
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
             ops.rotary_embedding(self.positions, q, k, D, self.cos_sin_cache, True)
             kc, vc = self.kv[li]
-            ops.reshape_and_cache(k.view(-1, nkv, D), v.view(-1, nkv, D), kc, vc, self.slot_mapping, "auto", 1.0)
+            ops.reshape_and_cache(k.view(-1, nkv, D), v.view(-1, nkv, D), kc, vc, self.slot_mapping, self.kv_dtype,
+                                  self.kv_scale)
             a = self.attention(q.view(-1, nh, D), li)
             h = self.gemm(a.view(-1, nh * D), lw["o"], "o")
             ops.fused_add_rms_norm(h, resid, lw["ln2"], 1e-5)
@@ -156,8 +221,17 @@ class Llama3Decode:
         return self.next_tokens
 
 
-def gemm_bytes(M, K, N, group):
-    return K * N // 2 + (K // group) * N * 2 + 2 * M * K + 2 * M * N
+def gemm_bytes(M, K, N, group, variant="int4"):
+    """Algorithmic bytes of one linear layer call."""
+    act = 2 * M * K + 2 * M * N
+    scales = (K // group) * N * 2
+    if variant == "sparse24":
+        return K * N // 4 + K * N // 8 + scales + act       # kept values + 2-bit positions
+    if variant == "fp8":
+        return K * N + M * K + 2 * M * N                      # fp8 weights, fp8 activations
+    if variant == "awq70b-tp8rank":
+        return K * N // 2 + scales + (K // group) * N // 2 + act  # + packed zero points
+    return K * N // 2 + scales + act
 
 
 def time_events(fn, reps):
@@ -200,9 +274,9 @@ def kernel_breakdown(model, reps=3):
 
         run()
         ms = time_events(run, reps) / nl
-        by = gemm_bytes(B, K, N, cfg["group"])
+        by = gemm_bytes(B, K, N, cfg["group"], model.variant)
         fl = 2.0 * B * K * N
-        out["int4_gemm_" + name] = dict(ms=ms, bytes=by, flops=fl, gbs=by / ms / 1e6, tflops=fl / ms / 1e9, launches=nl)
+        out[("int4_gemm_" if model.variant == "int4" else model.variant + "_gemm_") + name] = dict(ms=ms, bytes=by, flops=fl, gbs=by / ms / 1e6, tflops=fl / ms / 1e9, launches=nl)
     q = torch.randn(B, cfg["heads"], cfg["head"], dtype=torch.float16, device=model.dev) * 0.1
 
     def run_attn():
@@ -211,7 +285,8 @@ def kernel_breakdown(model, reps=3):
 
     run_attn()
     ms = time_events(run_attn, reps) / nl
-    by = 2 * B * model.L * cfg["kv_heads"] * cfg["head"] * 2 + 2 * B * cfg["heads"] * cfg["head"] * 2
+    kvb = 1 if model.kv_dtype == "fp8" else 2
+    by = 2 * B * model.L * cfg["kv_heads"] * cfg["head"] * kvb + 2 * B * cfg["heads"] * cfg["head"] * 2
     fl = 4.0 * B * model.L * cfg["heads"] * cfg["head"]
     out["paged_attention_" + ("v1" if model.use_v1 else "v2")] = dict(ms=ms, bytes=by, flops=fl, gbs=by / ms / 1e6,
                                                                       tflops=fl / ms / 1e9, launches=nl)
@@ -269,7 +344,7 @@ def pmc_traffic(kernels, args):
     try:
         prof = json.load(open(files[-1]))
         meta = prof.get("_workload", {"batch": 64, "ctx": 1024})
-        if meta.get("batch") != args.batch or meta.get("ctx") != args.ctx:
+        if meta.get("batch") != args.batch or meta.get("ctx") != args.ctx or args.config != meta.get("config", "int4"):
             return None, None
         # bytes of all the class's kernels (main kernel(s) + split-K reduce where one ran) per call of the op:
         # calls = launches of the main kernels
@@ -298,9 +373,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     from neuralmagic_vllm_amd import _custom_ops as ops
-    cfg = dict(LLAMA3_8B)
+    var = VARIANTS[args.config]
+    cfg = dict(var["model"])
+    if args.layers is None:
+        args.layers = cfg["layers"]
     cfg["layers"] = args.layers
-    model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev)
+    model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev, variant=args.config)
 
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()
@@ -344,13 +422,17 @@ def main():
         per_step = {k: v["ms"] * v["launches"] for k, v in kb.items()}
         # kernel classes: the four int4 GEMM launches of a layer are one kernel (marlin_gemm_kernel [+ its split-K reduce]);
         # per-launch figures are the mean over the four shapes, which is what rocprofv3's per-kernel average reports too.
-        gem = [v for k, v in kb.items() if k.startswith("int4_gemm")]
+        gem = [v for k, v in kb.items() if "_gemm_" in k]
+        gemm_kernels = {"int4": ("marlin_gemm_kernel", "marlin_decode_kernel", "splitk_reduce_kernel"),
+                        "sparse24": ("marlin_gemm_kernel", "splitk_reduce_kernel"),
+                        "fp8": ("scaled_mm_kernel", ),
+                        "awq70b-tp8rank": ("awq_gemm_kernel", "splitk_reduce_kernel")}[args.config]
         att = [v for k, v in kb.items() if k.startswith("paged_attention")][0]
         gem_ms = sum(v["ms"] for v in gem)
         classes = {
-            "marlin_gemm_kernel": dict(ms=gem_ms / len(gem), bytes=sum(v["bytes"] for v in gem) / len(gem),
-                                       flops=sum(v["flops"] for v in gem) / len(gem), step_ms=gem_ms * gem[0]["launches"],
-                                       prof=("marlin_gemm_kernel", "marlin_decode_kernel", "splitk_reduce_kernel")),
+            gemm_kernels[0]: dict(ms=gem_ms / len(gem), bytes=sum(v["bytes"] for v in gem) / len(gem),
+                                  flops=sum(v["flops"] for v in gem) / len(gem), step_ms=gem_ms * gem[0]["launches"],
+                                  prof=gemm_kernels),
             "paged_attention_kernel": dict(ms=att["ms"], bytes=att["bytes"], flops=att["flops"],
                                            step_ms=att["ms"] * att["launches"], prof=("paged_attention_kernel", )),
         }
@@ -359,7 +441,8 @@ def main():
         d["gbs"] = d["bytes"] / d["ms"] / 1e6
         d["tflops"] = d["flops"] / d["ms"] / 1e9
         # HBM-bound below the ridge (4*M flop/B vs ~312 flop/B machine balance)
-        hbm_bound = d["flops"] / d["bytes"] < MFMA_F16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+        mfma_peak = MFMA_F16_PEAK_TF * (2.0 if (args.config == "fp8" and dom != "paged_attention_kernel") else 1.0)  # fp8: 5 PF
+        hbm_bound = d["flops"] / d["bytes"] < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         traffic, traffic_src = pmc_traffic(d["prof"], args)
         if hbm_bound:
             roof = dict(bound="hbm", kernel=dom, achieved=round(d["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -367,12 +450,12 @@ def main():
                         avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_bytes_per_launch=int(d["bytes"]),
                         kernels_in_launch=list(d["prof"]))
         else:
-            roof = dict(bound="mfma", kernel=dom, achieved=round(d["tflops"], 1), peak=MFMA_F16_PEAK_TF, unit="TFLOP/s",
-                        frac=round(d["tflops"] / MFMA_F16_PEAK_TF, 4), traffic=traffic, traffic_source=traffic_src,
+            roof = dict(bound="mfma", kernel=dom, achieved=round(d["tflops"], 1), peak=mfma_peak, unit="TFLOP/s",
+                        frac=round(d["tflops"] / mfma_peak, 4), traffic=traffic, traffic_source=traffic_src,
                         avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_flops_per_launch=float(d["flops"]),
                         kernels_in_launch=list(d["prof"]))
         result = {
-            "metric": "decode tokens/sec, Llama-3-8B GPTQ-int4 (Marlin-format) TP=1",
+            "metric": var["metric"],
             "value": round(value, 1),
             "unit": "tokens/s",
             "n_gpus": world,
@@ -382,19 +465,20 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "fp8" if args.config == "fp8" else "f16",
             "data": "synthetic",
-            "config": {"workload": "Llama-3-8B GPTQ-int4 g128 decode step, TP=1 (configs[1])", "batch_per_gpu": args.batch,
-                       "context": args.ctx, "layers": args.layers, "kv_cache": "fp16 block 16", "hip_graph": graph is not None,
+            "config": {"workload": var["workload"], "batch_per_gpu": args.batch,
+                       "context": args.ctx, "layers": args.layers,
+                       "kv_cache": ("fp8-e4m3" if model.kv_dtype == "fp8" else "fp16") + " block 16", "hip_graph": graph is not None,
                        "parallelism": f"dp{world} (independent TP=1 replicas)"},
             "roofline": roof,
             "kernels": {k: {"us": round(v["ms"] * 1e3, 2), "GBps": round(v["gbs"], 1), "TFLOPs": round(v["tflops"], 2),
                             "step_share_ms": round(per_step[k], 3)} for k, v in kb.items()},
             "hot_path_share_of_step": round(sum(per_step.values()) / ms_per_step, 3),
         }
-        if args.sweep:
+        if args.sweep and args.config == "int4":
             result["sweep"] = sweep(ops, cfg, dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.config == "int4":  # the CPU port times the headline workload only
             result["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.ctx)
         print(json.dumps(result), flush=True)
     if dist is not None:

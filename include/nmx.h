@@ -194,10 +194,11 @@ int nmx_gptq_shuffle(int32_t* q_weight, int32_t* tmp, const int32_t* q_perm, int
  * Activation quantisation and the W8A8 scaled GEMM.
  * ---------------------------------------------------------------------------------------------------------- */
 /* static_scaled_fp8_quant / dynamic_scaled_fp8_quant (csrc/quantization/fp8/common.cu:129-165).
- * out u8 = e4m3fn(clamp(x * (1 / scale), +-448)). dynamic != 0: *scale (initialised <= 0 by the caller) is first set
- * to max|x| / 448 over the whole tensor. */
-int nmx_scaled_fp8_quant(void* out, const void* input, float* scale, int64_t numel, int dtype, int dynamic,
-                         nmx_stream_t stream);
+ * out u8 = e4m3fn(clamp(x * (1 / scale), +-448)). dynamic != 0: *scale is first set to max|x| / 448 over the whole
+ * tensor (whatever it held before: no zero-initialisation needed); that path needs >= 256 bytes of device scratch
+ * (per-workgroup maxima), ignored otherwise. */
+int nmx_scaled_fp8_quant(void* out, const void* input, float* scale, float* scratch, int64_t scratch_bytes,
+                         int64_t numel, int dtype, int dynamic, nmx_stream_t stream);
 /* static_scaled_int8_quant / dynamic_scaled_int8_quant (csrc/quantization/compressed_tensors/int8_quant_kernels.cu:75-115).
  * static: int8(rn(x / scales[0])); dynamic: per token scales[t] = max|x_t| / 127, int8(rn(x * 127 / max|x_t|)). */
 int nmx_scaled_int8_quant(void* out, const void* input, float* scales, int num_tokens, int hidden_size, int dtype,
@@ -207,8 +208,12 @@ int nmx_scaled_int8_quant(void* out, const void* input, float* scales, int num_t
  * column-major: pointer to B^T [n, k] rows (row stride ldb bytes); fp8 e4m3fn (is_fp8 != 0) or int8. Scales fp32,
  * numel 1 or m / n. ldc in elements. bias [n] in the output dtype or NULL. */
 int nmx_scaled_mm(void* out, const void* a, const void* b, const float* a_scales, int a_scales_numel,
-                  const float* b_scales, int b_scales_numel, const void* bias, int m, int n, int k, int64_t lda,
-                  int64_t ldb, int64_t ldc, int is_fp8, int out_dtype, nmx_stream_t stream);
+                  const float* b_scales, int b_scales_numel, const void* bias, void* scratch, int64_t scratch_bytes,
+                  int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int is_fp8, int out_dtype,
+                  nmx_stream_t stream);
+/* Bytes of split-K scratch (fp32 / int32 partial slabs) nmx_scaled_mm can use for this shape; 0 when it does not split.
+ * The caller owns the buffer (allocated outside graph capture); with less the kernel uses fewer splits. */
+int64_t nmx_scaled_mm_scratch_bytes(int m, int n, int k);
 /* cutlass_scaled_mm_supports_fp8 (scaled_mm_entry.cu:25-45): always 1 on gfx950 (native OCP fp8 MFMA). */
 int nmx_scaled_mm_supports_fp8(int capability);
 

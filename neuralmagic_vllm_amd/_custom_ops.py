@@ -657,8 +657,12 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, s
     if bias is not None and not (bias.numel() == n and bias.is_contiguous() and bias.dim() == 1 and bias.dtype == out_dtype):
         raise RuntimeError("cutlass_scaled_mm: bias must be a contiguous [N] tensor of the output dtype")
     out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    lib = _lib.lib()
+    lib.nmx_scaled_mm_scratch_bytes.restype = ctypes.c_int64
+    scratch = _get_scratch(a.device, int(lib.nmx_scaled_mm_scratch_bytes(c_int(m), c_int(n), c_int(k))))
     _lib.check(_lib.lib().nmx_scaled_mm(_p(out), _p(a), _p(b), _p(scale_a), c_int(scale_a.numel()), _p(scale_b),
-                                        c_int(scale_b.numel()), _p(bias), c_int(m), c_int(n), c_int(k),
+                                        c_int(scale_b.numel()), _p(bias), _p(scratch), c_i64(scratch.numel()),
+                                        c_int(m), c_int(n), c_int(k),
                                         c_i64(a.stride(0)), c_i64(b.stride(1)), c_i64(out.stride(0)),
                                         c_int(int(a.dtype == torch.float8_e4m3fn)), c_int(_dt(out)), _stream(a)))
     return out
@@ -678,14 +682,15 @@ def scaled_fp8_quant(
         output = torch.empty_like(input, dtype=torch.float8_e4m3fn)
     x = input if input.is_contiguous() else input.contiguous()
     if scale is None:
-        scale = torch.zeros(1, device=input.device, dtype=torch.float32)
+        scale = torch.empty(1, device=input.device, dtype=torch.float32)  # written by the kernel; no zero fill needed
         dynamic = 1
     else:
         dynamic = 0
         if scale.dtype != torch.float32 or scale.numel() != 1:
             raise RuntimeError("scaled_fp8_quant: scale must be a float32 scalar tensor")
-    _lib.check(_lib.lib().nmx_scaled_fp8_quant(_p(output), _p(x), _p(scale), c_i64(x.numel()), c_int(_dt(x)),
-                                               c_int(dynamic), _stream(x)))
+    scratch = _get_scratch(x.device, 256)
+    _lib.check(_lib.lib().nmx_scaled_fp8_quant(_p(output), _p(x), _p(scale), _p(scratch), c_i64(scratch.numel()),
+                                               c_i64(x.numel()), c_int(_dt(x)), c_int(dynamic), _stream(x)))
     return output, scale
 
 

@@ -8,14 +8,33 @@
 namespace {
 
 // ---- fp8 per-tensor quant (fp8/common.cu:24-125) ----------------------------------------------------------------
-// dynamic: scale = max|x| / 448, reduced with an integer atomicMax on the (non-negative) float bits; the caller
-// provides scale initialised to <= 0 (vllm/_custom_ops.py:316 uses zeros).
+// dynamic: scale = max|x| / 448 over the whole tensor. The reference reduces with atomicMax into a zero-initialised
+// scale; here pass 1 leaves one maximum per workgroup in a small scratch array and pass 2 lets every workgroup take the
+// maximum of those (<= 64 L2-resident floats) before it quantises - no atomics on one address (256 of them took the
+// first pass to 7.5 us), no need for the caller to zero the scale (a fill launch), same value bit for bit.
+constexpr int kAbsmaxBlocks = 64;
+
 template <typename T>
-__global__ void fp8_absmax_kernel(float* __restrict__ scale, const T* __restrict__ x, int64_t n) {
-  __shared__ float smem[17];
+__device__ __forceinline__ float absmax8(const T* p) {  // 8 consecutive elements (16 B for 2-byte types)
+  float m = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(Scalar<T>::to_f32(p[e])));
+  return m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void fp8_absmax_kernel(float* __restrict__ partial, const T* __restrict__ x, int64_t n,
+                                                          int64_t n8) {
+  __shared__ float smem[16];
   float m = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(Scalar<T>::to_f32(x[i])));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    struct alignas(sizeof(T) * 8) V { T e[8]; };
+    const V v = reinterpret_cast<const V*>(x)[i];
+    m = fmaxf(m, absmax8<T>(v.e));
+  }
+  for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    m = fmaxf(m, fabsf(Scalar<T>::to_f32(x[i])));
   m = wave_reduce_max(m);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) smem[wave] = m;
@@ -23,21 +42,41 @@ __global__ void fp8_absmax_kernel(float* __restrict__ scale, const T* __restrict
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmaxf(t, smem[w]);
-    atomicMax(reinterpret_cast<int*>(scale), __float_as_int(t / 448.0f));  // non-negative floats order like ints
+    partial[blockIdx.x] = t;
   }
 }
 
-template <typename T>
-__global__ void fp8_quant_kernel(uint8_t* __restrict__ out, const T* __restrict__ x, const float* __restrict__ scale,
-                                 int64_t n) {
-  const float inv = 1.0f / (*scale);  // the reference multiplies by the inverted scale (common.cu:91)
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float v = Scalar<T>::to_f32(x[i]) * inv;
+// DYNAMIC: scale = max(partial[0 .. nparts)) / 448, written to *scale by workgroup 0
+template <typename T, bool DYNAMIC>
+__global__ __launch_bounds__(1024) void fp8_quant_kernel(uint8_t* __restrict__ out, const T* __restrict__ x, float* __restrict__ scale,
+                                                         const float* __restrict__ partial, int nparts, int64_t n,
+                                                         int64_t n8) {
+  float sc;
+  if constexpr (DYNAMIC) {
+    float m = (int)(threadIdx.x & 63) < nparts ? partial[threadIdx.x & 63] : 0.f;  // nparts <= 64: one per lane
+    m = wave_reduce_max(m);
+    sc = m / 448.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale = sc;
+  } else {
+    sc = *scale;
+  }
+  const float inv = 1.0f / sc;  // the reference multiplies by the inverted scale (common.cu:91)
+  auto q = [&](T xv) -> uint32_t {
+    float v = Scalar<T>::to_f32(xv) * inv;
     asm volatile("" : "+v"(v));  // keep the product a separate fp32 rounding step (no fusion into the conversion)
     v = fmaxf(-448.0f, fminf(v, 448.0f));
-    out[i] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xff);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xffu;
+  };
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    struct alignas(sizeof(T) * 8) V { T e[8]; };
+    const V v = reinterpret_cast<const V*>(x)[i];
+    u32x2 o;
+    o[0] = q(v.e[0]) | (q(v.e[1]) << 8) | (q(v.e[2]) << 16) | (q(v.e[3]) << 24);
+    o[1] = q(v.e[4]) | (q(v.e[5]) << 8) | (q(v.e[6]) << 16) | (q(v.e[7]) << 24);
+    reinterpret_cast<u32x2*>(out)[i] = o;
   }
+  for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint8_t)q(x[i]);
 }
 
 // ---- int8 quant (compressed_tensors/int8_quant_kernels.cu:8-71) -------------------------------------------------
@@ -77,8 +116,12 @@ __global__ void int8_quant_kernel(int8_t* __restrict__ out, const T* __restrict_
 // out[M,N] = cast(a_scale (.) (A . B) (.) b_scale) (+ bias). A [M,K] row-major, B column-major = Bt [N,K] row-major:
 // both operands are K-contiguous, i.e. already in MFMA fragment order. Lane (g, i) of a 16-row tile loads 16
 // consecutive k-bytes (k0 + 16 g ..) of its row and feeds two MFMA 16x16x32 (fp8) / one 16x16x64 (int8) k-steps.
-// Workgroup: 4 waves = 4 K-slices of one 64-column x (16 MT)-row tile, reduced through LDS.
-// grid (ceil(N / 64), k_splits (1 for now), ceil(M / (16 MT)))
+// Workgroup: 4 waves = 4 contiguous K-slices of one 64-column x (16 MT)-row tile, reduced through LDS. Every wave
+// keeps PF 64-byte k-steps of both operands in flight (a register ring; without it each step paid a full memory round
+// trip and the kernel was latency-bound: 43 us for 25 MB at M = 64). K is also split across gridDim.y workgroups when
+// the tile count alone leaves CUs idle (decode: N / 64 = 64..96 tiles): raw fp32 / int32 partial slabs in a scratch
+// buffer, summed in a fixed order by scaled_mm_reduce_kernel, which then applies the scale / bias epilogue.
+// grid (ceil(N / 64), k_splits, ceil(M / (16 MT)))
 struct MmParams {
   const uint8_t* a;
   const uint8_t* bt;
@@ -89,12 +132,35 @@ struct MmParams {
   int M, N, K;
   int64_t lda, ldb, ldc;
   int a_per_row, b_per_col;
+  int k_splits;
+  void* partial;  // [k_splits][M][N] fp32 (fp8) / int32 (int8)
 };
 
-template <typename out_t, bool FP8, int MT>
-__global__ __launch_bounds__(256) void scaled_mm_kernel(const MmParams p) {
+// four consecutive output columns n .. n + 3 of row m: scales, bias, ONE 8-byte store (n % 4 == 0, ldc % 16 == 0)
+template <typename out_t, typename acc_t>
+__device__ __forceinline__ void mm_epilogue4(const MmParams& p, acc_t acc, int m, int n) {
+  const float sa = p.a_scales[p.a_per_row ? m : 0];
+  union { out_t h[4]; u32x2 u; } o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float sb = p.b_scales[p.b_per_col ? n + r : 0];
+    const float v = sa * (sb * (float)acc[r]);  // tests/kernels/test_cutlass.py:35-47
+    o.h[r] = Scalar<out_t>::from_f32(v);
+  }
+  if (p.bias != nullptr) {
+    union { out_t h[4]; u32x2 u; } b;
+    b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const out_t*>(p.bias) + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.h[r] = Scalar<out_t>::from_f32(Scalar<out_t>::to_f32(o.h[r]) + Scalar<out_t>::to_f32(b.h[r]));
+  }
+  *reinterpret_cast<u32x2*>(reinterpret_cast<out_t*>(p.out) + (int64_t)m * p.ldc + n) = o.u;
+}
+
+template <typename out_t, bool FP8, int MT, bool TAIL>
+__global__ __launch_bounds__(256, 2) void scaled_mm_kernel(const MmParams p) {
   constexpr int NT = 4;  // 16-column tiles per wave (64 columns)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PF = 4;  // k-steps in flight per wave
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 16 * MT;
   const int K = p.K;
@@ -105,37 +171,90 @@ __global__ __launch_bounds__(256) void scaled_mm_kernel(const MmParams p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mt][t] = acc_t{0, 0, 0, 0};
 
-  // K is split in 64-byte steps over the 4 waves (interleaved)
+  // this workgroup's range of 64-byte k-steps; its 4 waves interleave inside it
   const int steps = (K + 63) / 64;
-  for (int s = wave; s < steps; s += 4) {
-    const int k = s * 64 + 16 * g;
-    const bool kok = k < K;  // K % 16 == 0 is required
-    u32x4 bf[NT], af[MT];
+  const int per = (steps + p.k_splits - 1) / p.k_splits;
+  const int sb = min((int)blockIdx.y * per, steps), se = min(sb + per, steps);
+
+  // Buffer loads: per-lane byte offset of the row (rows past the matrix get an offset beyond the descriptor and read as
+  // zeros), wave-uniform k offset in an SGPR. No value is touched between the load and its MFMA, so nothing forces an
+  // early wait and the ring really stays in flight (a select on the loaded value right after the load did exactly that).
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bt), 0, (int)((int64_t)p.N * p.ldb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.a), 0, (int)((int64_t)p.M * p.lda), 0x00020000);
+  int b_voff[NT], a_voff[MT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = n0 + 16 * t + li;
-      bf[t] = (kok && n < p.N) ? *reinterpret_cast<const u32x4*>(p.bt + (int64_t)n * p.ldb + k) : u32x4{0, 0, 0, 0};
-    }
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + li;
+    b_voff[t] = n < p.N ? (int)(n * p.ldb + 16 * g) : (int)0xfffffff0u;
+  }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = m0 + 16 * mt + li;
-      af[mt] = (kok && m < p.M) ? *reinterpret_cast<const u32x4*>(p.a + (int64_t)m * p.lda + k) : u32x4{0, 0, 0, 0};
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + li;
+    a_voff[mt] = m < p.M ? (int)(m * p.lda + 16 * g) : (int)0xfffffff0u;
+  }
+  struct Step { u32x4 bf[NT]; u32x4 af[MT]; };
+  auto load = [&](int s, Step& r) {
+    const int soff = min(s, steps - 1) * 64;  // past the range: the last step again (never computed on)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r.bf[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff[t], soff, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) r.af[mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], soff, 0);
+    if constexpr (TAIL) {
+      // K % 64 != 0: the lanes of the last step that start at or beyond K read the next row; drop them
+      const bool kok = s * 64 + 16 * g < K;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) r.bf[t] = kok ? r.bf[t] : u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) r.af[mt] = kok ? r.af[mt] : u32x4{0, 0, 0, 0};
+    } else {
+      __builtin_amdgcn_sched_barrier(0);  // same queue order in the prologue and in the loop
     }
+  };
+  auto compute = [&](const Step& r) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         // weights as the MFMA "A" operand (rows = columns of the output), activations as "B": D[n][m]
         if constexpr (FP8) {
-          const long b0 = (long)(((uint64_t)bf[t][1] << 32) | bf[t][0]), b1 = (long)(((uint64_t)bf[t][3] << 32) | bf[t][2]);
-          const long a0 = (long)(((uint64_t)af[mt][1] << 32) | af[mt][0]), a1 = (long)(((uint64_t)af[mt][3] << 32) | af[mt][2]);
+          const long b0 = (long)(((uint64_t)r.bf[t][1] << 32) | r.bf[t][0]), b1 = (long)(((uint64_t)r.bf[t][3] << 32) | r.bf[t][2]);
+          const long a0 = (long)(((uint64_t)r.af[mt][1] << 32) | r.af[mt][0]), a1 = (long)(((uint64_t)r.af[mt][3] << 32) | r.af[mt][2]);
           acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b0, a0, acc[mt][t], 0, 0, 0);
           acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b1, a1, acc[mt][t], 0, 0, 0);
         } else {
-          acc[mt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bf[t]), __builtin_bit_cast(i32x4, af[mt]),
+          acc[mt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, r.bf[t]), __builtin_bit_cast(i32x4, r.af[mt]),
                                                             acc[mt][t], 0, 0, 0);
         }
       }
+  };
+  {
+    // each wave a CONTIGUOUS quarter of the workgroup's steps: consecutive 64-byte pieces of a row (the two halves of a
+    // 128-byte line) are then requested back to back by the same wave
+    const int pw = (se - sb + 3) / 4;
+    const int ws = min(sb + wave * pw, se), we = min(ws + pw, se);
+    // Every workgroup starts its sweep at a different k (rotated by its column-tile index, wrapping inside the wave's
+    // slice): rows of B are K bytes apart, so workgroups that all read the same k offset of their rows at the same time
+    // concentrate on the few memory channels those addresses share.
+    const int len = we - ws;
+    const int rot = len > 0 ? (int)((blockIdx.x * 5u) % (unsigned)len) : 0;
+    auto step_of = [&](int j) {  // j-th step of this wave's sweep; past the end: a valid step (loaded, never used)
+      int t = min(j, len - 1) + rot;
+      t = t >= len ? t - len : t;
+      return ws + t;
+    };
+    Step ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load(step_of(i), ring[i]);
+    // whole rounds of PF steps; a step past the slice is skipped (MFMAs only: the load pattern stays the same)
+    for (int j = 0; j < len; j += PF) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        if (j + i < len) compute(ring[i]);
+        load(step_of(j + i + PF), ring[i]);
+      }
+    }
   }
 
   // reduce the 4 K-slices through LDS
@@ -157,54 +276,107 @@ __global__ __launch_bounds__(256) void scaled_mm_kernel(const MmParams p) {
       for (int t = 0; t < NT; ++t) acc[mt][t] += red[((w * MT + mt) * NT + t) * 64 + lane];
 
   // D layout: col = lane & 15 = activation row m, rows 4 g + r = output columns n0 + 16 t + 4 g + r
-  out_t* out = reinterpret_cast<out_t*>(p.out);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + 16 * mt + li;
     if (m >= p.M) continue;
-    const float sa = p.a_scales[p.a_per_row ? m : 0];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 16 * t + 4 * g + r;
-        if (n >= p.N) continue;
-        const float sb = p.b_scales[p.b_per_col ? n : 0];
-        float v = sa * (sb * (float)acc[mt][t][r]);  // tests/kernels/test_cutlass.py:35-47
-        out_t o = Scalar<out_t>::from_f32(v);
-        if (p.bias != nullptr) o = Scalar<out_t>::from_f32(Scalar<out_t>::to_f32(o) + Scalar<out_t>::to_f32(reinterpret_cast<const out_t*>(p.bias)[n]));
-        out[(int64_t)m * p.ldc + n] = o;
+      const int n = n0 + 16 * t + 4 * g;
+      if (n >= p.N) continue;  // N % 16 == 0: the 4 columns of a lane are inside or outside together
+      if (p.k_splits > 1) {
+        *reinterpret_cast<acc_t*>(reinterpret_cast<char*>(p.partial) + (((int64_t)blockIdx.y * p.M + m) * p.N + n) * 4) = acc[mt][t];
+      } else {
+        mm_epilogue4<out_t>(p, acc[mt][t], m, n);
       }
     }
   }
 }
 
+// out = epilogue(sum_s partial[s]); 4 columns per thread; summation order s = 0, 1, ... (deterministic)
 template <typename out_t, bool FP8>
-int launch_mm(const MmParams& p, hipStream_t stream) {
+__global__ void scaled_mm_reduce_kernel(const MmParams p) {
+  using acc_t = typename std::conditional<FP8, f32x4, i32x4>::type;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t mn4 = (int64_t)p.M * p.N / 4;
+  if (i >= mn4) return;
+  const acc_t* part = reinterpret_cast<const acc_t*>(p.partial);
+  acc_t acc = part[i];
+  for (int s = 1; s < p.k_splits; ++s) acc += part[(int64_t)s * mn4 + i];
+  const int m = (int)((i * 4) / p.N), n = (int)((i * 4) % p.N);
+  mm_epilogue4<out_t>(p, acc, m, n);
+}
+
+// K splits: fill the chip when the output tiles alone do not, keeping >= 4 k-steps per wave
+inline int mm_splits(int M, int N, int K) {
+  const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  const int tiles = ceil_div(N, 64) * ceil_div(M, 16 * mt), steps = ceil_div(K, 64);
+  int sp = 1;
+  while (tiles * sp < 192 && sp < 16 && steps / (4 * sp * 2) >= 4) sp *= 2;
+  return sp;
+}
+
+template <typename out_t, bool FP8>
+int launch_mm(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
   const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
-  dim3 grid(ceil_div(p.N, 64), 1, ceil_div(p.M, 16 * mt));
+  p.k_splits = mm_splits(p.M, p.N, p.K);
+  const int64_t per = (int64_t)p.M * p.N * 4;
+  if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to what fits
+    const int fit = scratch == nullptr ? 1 : (int)std::min<int64_t>(p.k_splits, scratch_bytes / per);
+    p.k_splits = std::max(1, fit);
+  }
+  p.partial = scratch;
+  dim3 grid(ceil_div(p.N, 64), p.k_splits, ceil_div(p.M, 16 * mt));
   const size_t smem = (size_t)3 * mt * 4 * 64 * 16;
-  switch (mt) {
-    case 1: scaled_mm_kernel<out_t, FP8, 1><<<grid, 256, smem, stream>>>(p); break;
-    case 2: scaled_mm_kernel<out_t, FP8, 2><<<grid, 256, smem, stream>>>(p); break;
-    default: scaled_mm_kernel<out_t, FP8, 4><<<grid, 256, smem, stream>>>(p); break;
+  if (p.K % 64 == 0) {
+    switch (mt) {
+      case 1: scaled_mm_kernel<out_t, FP8, 1, false><<<grid, 256, smem, stream>>>(p); break;
+      case 2: scaled_mm_kernel<out_t, FP8, 2, false><<<grid, 256, smem, stream>>>(p); break;
+      default: scaled_mm_kernel<out_t, FP8, 4, false><<<grid, 256, smem, stream>>>(p); break;
+    }
+  } else {
+    switch (mt) {
+      case 1: scaled_mm_kernel<out_t, FP8, 1, true><<<grid, 256, smem, stream>>>(p); break;
+      case 2: scaled_mm_kernel<out_t, FP8, 2, true><<<grid, 256, smem, stream>>>(p); break;
+      default: scaled_mm_kernel<out_t, FP8, 4, true><<<grid, 256, smem, stream>>>(p); break;
+    }
   }
   NMX_LAUNCH_CHECK();
+  if (p.k_splits > 1) {
+    const int64_t mn4 = (int64_t)p.M * p.N / 4;
+    scaled_mm_reduce_kernel<out_t, FP8><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(p);
+    NMX_LAUNCH_CHECK();
+  }
   return NMX_OK;
 }
 
 }  // namespace
 
-extern "C" int nmx_scaled_fp8_quant(void* out, const void* input, float* scale, int64_t numel, int dtype, int dynamic,
-                                    nmx_stream_t stream_) {
+extern "C" int nmx_scaled_fp8_quant(void* out, const void* input, float* scale, float* scratch, int64_t scratch_bytes,
+                                    int64_t numel, int dtype, int dynamic, nmx_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (numel == 0) return NMX_OK;
+  const int esz = dtype == NMX_F32 ? 4 : 2;
+  // 8 elements per thread and access when the pointers allow it (n8 = number of such vectors), else element-wise
+  const bool vec = (uintptr_t)input % (8 * esz) == 0 && (uintptr_t)out % 8 == 0;
+  const int64_t n8 = vec ? numel / 8 : 0;
   const int threads = 1024;
-  const int blocks = (int)std::min<int64_t>(ceil_div64(numel, threads), 1024);
-#define NMX_FP8Q(T)                                                                                        \
-  do {                                                                                                     \
-    if (dynamic) fp8_absmax_kernel<T><<<blocks, threads, 0, stream>>>(scale, (const T*)input, numel);      \
-    fp8_quant_kernel<T><<<blocks, threads, 0, stream>>>((uint8_t*)out, (const T*)input, scale, numel);     \
+  // one 16-byte piece per thread and iteration; at most kAbsmaxBlocks workgroups (one partial maximum per lane of a wave)
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(vec ? numel / 8 : numel, threads), kAbsmaxBlocks));
+  if (dynamic)
+    NMX_CHECK(scratch != nullptr && scratch_bytes >= (int64_t)kAbsmaxBlocks * 4, NMX_ERR_INVALID_ARG,
+              "scaled_fp8_quant: dynamic scaling needs %d bytes of scratch", kAbsmaxBlocks * 4);
+  const int qblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(vec ? numel / 8 : numel, threads), 1024));
+#define NMX_FP8Q(T)                                                                                              \
+  do {                                                                                                           \
+    if (dynamic) {                                                                                               \
+      fp8_absmax_kernel<T><<<blocks, threads, 0, stream>>>(scratch, (const T*)input, numel, n8);                  \
+      fp8_quant_kernel<T, true><<<qblocks, threads, 0, stream>>>((uint8_t*)out, (const T*)input, scale, scratch, \
+                                                                 blocks, numel, n8);                             \
+    } else {                                                                                                     \
+      fp8_quant_kernel<T, false><<<qblocks, threads, 0, stream>>>((uint8_t*)out, (const T*)input, scale, nullptr, \
+                                                                  0, numel, n8);                                 \
+    }                                                                                                            \
   } while (0)
   switch (dtype) {
     case NMX_F32: NMX_FP8Q(float); break;
@@ -238,9 +410,16 @@ extern "C" int nmx_scaled_int8_quant(void* out, const void* input, float* scales
   return NMX_OK;
 }
 
+extern "C" int64_t nmx_scaled_mm_scratch_bytes(int m, int n, int k) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  const int sp = mm_splits(m, n, k);
+  return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
+}
+
 extern "C" int nmx_scaled_mm(void* out, const void* a, const void* b, const float* a_scales, int a_scales_numel,
-                             const float* b_scales, int b_scales_numel, const void* bias, int m, int n, int k,
-                             int64_t lda, int64_t ldb, int64_t ldc, int is_fp8, int out_dtype, nmx_stream_t stream) {
+                             const float* b_scales, int b_scales_numel, const void* bias, void* scratch,
+                             int64_t scratch_bytes, int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int is_fp8,
+                             int out_dtype, nmx_stream_t stream) {
   // checks mirror cutlass_w8a8/scaled_mm_entry.cu:59-76
   NMX_CHECK(a_scales_numel == 1 || a_scales_numel == m, NMX_ERR_INVALID_ARG, "a_scales.numel() must be 1 or a.size(0)");
   NMX_CHECK(b_scales_numel == 1 || b_scales_numel == n, NMX_ERR_INVALID_ARG, "b_scales.numel() must be 1 or b.size(1)");
@@ -248,11 +427,17 @@ extern "C" int nmx_scaled_mm(void* out, const void* a, const void* b, const floa
   NMX_CHECK(ldb % 16 == 0 && ldc % 16 == 0 && lda % 16 == 0, NMX_ERR_INVALID_ARG, "scaled_mm: 16-byte row alignment required");
   NMX_CHECK(out_dtype == NMX_F16 || out_dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "scaled_mm: output must be float16 or bfloat16");
   NMX_CHECK(((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0), NMX_ERR_INVALID_ARG, "scaled_mm: operands must be 16-byte aligned");
+  NMX_CHECK(((uintptr_t)out % 8 == 0) && ((uintptr_t)bias % 8 == 0), NMX_ERR_INVALID_ARG, "scaled_mm: out and bias must be 8-byte aligned");
   if (m == 0 || n == 0) return NMX_OK;
+  NMX_CHECK((int64_t)n * ldb < (1ll << 31) && (int64_t)m * lda < (1ll << 31), NMX_ERR_UNSUPPORTED,
+            "scaled_mm: operands of 2 GiB or more are not supported");
   MmParams p{(const uint8_t*)a, (const uint8_t*)b, out, a_scales, b_scales, bias, m, n, k, lda, ldb, ldc,
-             a_scales_numel > 1 ? 1 : 0, b_scales_numel > 1 ? 1 : 0};
-  if (out_dtype == NMX_F16) return is_fp8 ? launch_mm<f16, true>(p, (hipStream_t)stream) : launch_mm<f16, false>(p, (hipStream_t)stream);
-  return is_fp8 ? launch_mm<bf16, true>(p, (hipStream_t)stream) : launch_mm<bf16, false>(p, (hipStream_t)stream);
+             a_scales_numel > 1 ? 1 : 0, b_scales_numel > 1 ? 1 : 0, 1, nullptr};
+  if (out_dtype == NMX_F16)
+    return is_fp8 ? launch_mm<f16, true>(p, scratch, scratch_bytes, (hipStream_t)stream)
+                  : launch_mm<f16, false>(p, scratch, scratch_bytes, (hipStream_t)stream);
+  return is_fp8 ? launch_mm<bf16, true>(p, scratch, scratch_bytes, (hipStream_t)stream)
+                : launch_mm<bf16, false>(p, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 extern "C" int nmx_scaled_mm_supports_fp8(int capability) {
