@@ -3,6 +3,8 @@
 // Replaces csrc/quantization/fp8/common.cu, csrc/quantization/compressed_tensors/int8_quant_kernels.cu and the
 // semantics of csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu (CUTLASS itself is not ported: the contraction is
 // a hand-written MFMA kernel; fp8 is OCP e4m3fn, the gfx950-native format).
+#include <stdlib.h>
+
 #include "nmx_common.h"
 
 namespace {
@@ -293,6 +295,143 @@ __global__ __launch_bounds__(256, 2) void scaled_mm_kernel(const MmParams p) {
   }
 }
 
+// ---- the same contraction with both operands staged through LDS in full 128-byte lines (K % 128 == 0) ----------------
+// The fragment-shaped loads of scaled_mm_kernel (16 rows x 64 B per wave instruction) keep the CU's texture-address
+// path busy ~3.5x longer per instruction than line-shaped ones (measured: ~140 vs ~38 cycles; the guide's M = 256
+// projection study reports TA_BUSY 2x for the same shape). Here a wave instruction reads 8 rows x one whole 128-byte
+// line; the 16-byte chunks go to a wave-private LDS image [row][128 B] with chunk c stored at c ^ ((row >> 1) & 7)
+// (ds_write_b128 and the ds_read_b128 of 16 consecutive rows are then both bank-conflict free) and the MFMA fragments
+// (row i, bytes 64 q + 16 g) are read back from there. No workgroup barrier in the loop: every wave owns a K slice, its
+// image and its registers; LDS operations of one wave complete in order. The next stage's global loads are issued
+// before the current stage's MFMAs (two register sets).
+// grid (ceil(N / 64), k_splits, ceil(M / (16 MT))), 4 waves, LDS 4 x (64 + 16 MT) x 128 B.
+template <typename out_t, bool FP8, int MT>
+__global__ __launch_bounds__(256, 2) void scaled_mm_lds_kernel(const MmParams p) {
+  constexpr int NT = 4;
+  constexpr int BROWS = 64, AROWS = 16 * MT;
+  constexpr int BI = BROWS / 8, AI = AROWS / 8;  // load instructions per stage (8 rows x 128 B each)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int lr = lane >> 3, lc = lane & 7;  // load role: row within the 8-row piece, 16-byte chunk of the line
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 16 * MT;
+  using acc_t = typename std::conditional<FP8, f32x4, i32x4>::type;
+  acc_t acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[mt][t] = acc_t{0, 0, 0, 0};
+
+  const int stages = p.K / 128;
+  const int per = (stages + p.k_splits - 1) / p.k_splits;
+  const int sb = min((int)blockIdx.y * per, stages), se = min(sb + per, stages);
+  const int pw = (se - sb + 3) / 4;
+  const int ws = min(sb + wave * pw, se), we = min(ws + pw, se);
+  const int len = we - ws;
+
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bt), 0, (int)((int64_t)p.N * p.ldb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.a), 0, (int)((int64_t)p.M * p.lda), 0x00020000);
+  int b_voff[BI], a_voff[AI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int n = n0 + 8 * j + lr;
+    b_voff[j] = n < p.N ? (int)(n * p.ldb + 16 * lc) : (int)0xfffffff0u;  // rows past the matrix read as zeros
+  }
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int m = m0 + 8 * j + lr;
+    a_voff[j] = m < p.M ? (int)(m * p.lda + 16 * lc) : (int)0xfffffff0u;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* img = smem + wave * ((BROWS + AROWS) * 128);
+  // row r, chunk c -> byte offset inside the image
+  auto slot = [](int r, int c) { return r * 128 + 16 * (c ^ ((r >> 1) & 7)); };
+
+  struct Stage { u32x4 b[BI]; u32x4 a[AI]; };
+  auto load = [&](int s, Stage& r) {
+    const int soff = min(s, stages - 1) * 128;  // past the slice: a valid stage again (never used)
+#pragma unroll
+    for (int j = 0; j < BI; ++j) r.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff[j], soff, 0);
+#pragma unroll
+    for (int j = 0; j < AI; ++j) r.a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[j], soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute = [&](const Stage& r) {
+#pragma unroll
+    for (int j = 0; j < BI; ++j) *reinterpret_cast<u32x4*>(img + slot(8 * j + lr, lc)) = r.b[j];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) *reinterpret_cast<u32x4*>(img + slot(BROWS + 8 * j + lr, lc)) = r.a[j];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {  // the two 64-byte halves of the line
+      u32x4 bf[NT], af[MT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const u32x4*>(img + slot(16 * t + li, 4 * q + g));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(img + slot(BROWS + 16 * mt + li, 4 * q + g));
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if constexpr (FP8) {
+            const long b0 = (long)(((uint64_t)bf[t][1] << 32) | bf[t][0]), b1 = (long)(((uint64_t)bf[t][3] << 32) | bf[t][2]);
+            const long a0 = (long)(((uint64_t)af[mt][1] << 32) | af[mt][0]), a1 = (long)(((uint64_t)af[mt][3] << 32) | af[mt][2]);
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b0, a0, acc[mt][t], 0, 0, 0);
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b1, a1, acc[mt][t], 0, 0, 0);
+          } else {
+            acc[mt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bf[t]), __builtin_bit_cast(i32x4, af[mt]),
+                                                              acc[mt][t], 0, 0, 0);
+          }
+        }
+    }
+  };
+  if (len > 0) {
+    Stage r0, r1;
+    load(ws, r0);
+    load(ws + 1, r1);
+    // pairs of stages, branch-free load pattern; a stage past the slice is loaded (clamped) but not computed
+    for (int j = 0; j < len; j += 2) {
+      compute(r0);
+      load(ws + j + 2, r0);
+      if (j + 1 < len) compute(r1);
+      load(ws + j + 3, r1);
+    }
+  }
+
+  // reduce the 4 K-slices through LDS (the images are dead: every wave is past its last fragment read at the barrier)
+  __syncthreads();
+  acc_t* red = reinterpret_cast<acc_t*>(smem);  // [3][MT][NT][64]
+  if (wave > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) red[(((wave - 1) * MT + mt) * NT + t) * 64 + lane] = acc[mt][t];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[mt][t] += red[((w * MT + mt) * NT + t) * 64 + lane];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + 16 * t + 4 * g;
+      if (n >= p.N) continue;
+      if (p.k_splits > 1) {
+        *reinterpret_cast<acc_t*>(reinterpret_cast<char*>(p.partial) + (((int64_t)blockIdx.y * p.M + m) * p.N + n) * 4) = acc[mt][t];
+      } else {
+        mm_epilogue4<out_t>(p, acc[mt][t], m, n);
+      }
+    }
+  }
+}
+
 // out = epilogue(sum_s partial[s]); 4 columns per thread; summation order s = 0, 1, ... (deterministic)
 template <typename out_t, bool FP8>
 __global__ void scaled_mm_reduce_kernel(const MmParams p) {
@@ -328,7 +467,15 @@ int launch_mm(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t str
   p.partial = scratch;
   dim3 grid(ceil_div(p.N, 64), p.k_splits, ceil_div(p.M, 16 * mt));
   const size_t smem = (size_t)3 * mt * 4 * 64 * 16;
-  if (p.K % 64 == 0) {
+  if (p.K % 128 == 0 && getenv("NMX_MM_NO_LDS") == nullptr) {
+    const size_t img = (size_t)4 * (64 + 16 * mt) * 128;
+    const size_t smem_l = std::max(img, smem);
+    switch (mt) {
+      case 1: scaled_mm_lds_kernel<out_t, FP8, 1><<<grid, 256, smem_l, stream>>>(p); break;
+      case 2: scaled_mm_lds_kernel<out_t, FP8, 2><<<grid, 256, smem_l, stream>>>(p); break;
+      default: scaled_mm_lds_kernel<out_t, FP8, 4><<<grid, 256, smem_l, stream>>>(p); break;
+    }
+  } else if (p.K % 64 == 0) {
     switch (mt) {
       case 1: scaled_mm_kernel<out_t, FP8, 1, false><<<grid, 256, smem, stream>>>(p); break;
       case 2: scaled_mm_kernel<out_t, FP8, 2, false><<<grid, 256, smem, stream>>>(p); break;
