@@ -60,8 +60,15 @@ __global__ void rms_norm_vec_kernel(T* __restrict__ out, T* __restrict__ input, 
   const int64_t row = (int64_t)blockIdx.x * hidden;
   const int nvec = hidden / 8;
   union V { u32x4 u; T e[8]; };
-  V x[VPT];
+  V x[VPT], w[VPT];
   float var = 0.f;
+  // the weight vectors are requested together with the row: behind the block reduction (a barrier the compiler does not
+  // move loads across) their L2 round trip would be exposed, and this kernel is all latency (4 KB per workgroup)
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = threadIdx.x + k * blockDim.x;
+    if (v < nvec) w[k].u = *reinterpret_cast<const u32x4*>(weight + v * 8);
+  }
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int v = threadIdx.x + k * blockDim.x;
@@ -87,10 +94,9 @@ __global__ void rms_norm_vec_kernel(T* __restrict__ out, T* __restrict__ input, 
   for (int k = 0; k < VPT; ++k) {
     const int v = threadIdx.x + k * blockDim.x;
     if (v < nvec) {
-      V w, o;
-      w.u = *reinterpret_cast<const u32x4*>(weight + v * 8);
+      V o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * s), w.e[j]);
+      for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * s), w[k].e[j]);
       *reinterpret_cast<u32x4*>(out + row + v * 8) = o.u;
     }
   }
@@ -119,6 +125,40 @@ __global__ void rotary_kernel(const int64_t* __restrict__ positions, T* __restri
     const T x = arr[xi], y = arr[yi];
     arr[xi] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(x, c)) - Scalar<T>::to_f32(rnd_mul<T>(y, s)));
     arr[yi] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(y, c)) + Scalar<T>::to_f32(rnd_mul<T>(x, s)));
+  }
+}
+
+// NeoX pairing, 2-byte types, everything 16-byte aligned: one thread = 8 consecutive rotary indices of one head (x run,
+// y run, cos run, sin run = four 16-byte accesses). The x / y loads do not depend on the position, so they are issued
+// before the positions -> cos/sin chain instead of behind it. Same arithmetic, element by element, as rotary_kernel.
+template <typename T>
+__global__ void rotary_neox_vec_kernel(const int64_t* __restrict__ positions, T* __restrict__ query, T* __restrict__ key,
+                                       const T* __restrict__ cos_sin_cache, const int64_t* __restrict__ offsets, int rot_dim,
+                                       int64_t q_stride, int64_t k_stride, int num_heads, int num_kv_heads, int head_size) {
+  const int64_t tok = blockIdx.x;
+  const int embed = rot_dim / 2, vper = embed / 8;  // 16-byte vectors per head half
+  const int nvec = (num_heads + num_kv_heads) * vper;
+  union V { u32x4 u; T e[8]; };
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+    const int head = i / vper, ro = (i % vper) * 8;
+    T* arr = (head < num_heads ? query + tok * q_stride + (int64_t)head * head_size
+                               : key + tok * k_stride + (int64_t)(head - num_heads) * head_size);
+    V x, y, c, sn;
+    x.u = *reinterpret_cast<const u32x4*>(arr + ro);
+    y.u = *reinterpret_cast<const u32x4*>(arr + embed + ro);
+    int64_t pos = positions[tok];
+    if (offsets != nullptr) pos += offsets[tok];
+    const T* cache = cos_sin_cache + pos * rot_dim;
+    c.u = *reinterpret_cast<const u32x4*>(cache + ro);
+    sn.u = *reinterpret_cast<const u32x4*>(cache + embed + ro);
+    V ox, oy;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ox.e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(x.e[j], c.e[j])) - Scalar<T>::to_f32(rnd_mul<T>(y.e[j], sn.e[j])));
+      oy.e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(y.e[j], c.e[j])) + Scalar<T>::to_f32(rnd_mul<T>(x.e[j], sn.e[j])));
+    }
+    *reinterpret_cast<u32x4*>(arr + ro) = ox.u;
+    *reinterpret_cast<u32x4*>(arr + embed + ro) = oy.u;
   }
 }
 
@@ -257,6 +297,16 @@ static int launch_rotary(const int64_t* positions, void* query, void* key, const
                          int rot_dim, int64_t q_stride, int64_t k_stride, int num_tokens, int num_heads,
                          int num_kv_heads, int head_size, int is_neox, hipStream_t stream) {
   const int work = (num_heads + num_kv_heads) * rot_dim / 2;
+  const bool vec = is_neox && sizeof(T) == 2 && rot_dim % 16 == 0 && head_size % 8 == 0 && q_stride % 8 == 0 && k_stride % 8 == 0 &&
+                   (((uintptr_t)query | (uintptr_t)key | (uintptr_t)cache) % 16 == 0);
+  if (vec) {
+    const int nvec = work / 8;
+    const int vthreads = std::min(512, std::max(64, ((nvec + 63) / 64) * 64));
+    rotary_neox_vec_kernel<T><<<num_tokens, vthreads, 0, stream>>>(positions, (T*)query, (T*)key, (const T*)cache, offsets, rot_dim,
+                                                                 q_stride, k_stride, num_heads, num_kv_heads, head_size);
+    NMX_LAUNCH_CHECK();
+    return NMX_OK;
+  }
   const int threads = std::min(512, std::max(64, ((work + 63) / 64) * 64));
   if (is_neox)
     rotary_kernel<T, true><<<num_tokens, threads, 0, stream>>>(positions, (T*)query, (T*)key, (const T*)cache, offsets, rot_dim,
