@@ -19,6 +19,7 @@
 //
 // HBM-bound: algorithmic bytes per (sequence, kv head) = 2 * seq_len * D * sizeof(cache element).
 #include <float.h>
+#include <stdlib.h>
 
 #include "nmx_common.h"
 
@@ -560,9 +561,8 @@ int launch_attn_f32(const AttnParams& p, int kv_dtype, int head_size, int num_se
   return NMX_OK;
 }
 
-template <typename scalar_t, int KV, int D>
-int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream_t stream) {
-  constexpr int NW = 4;
+template <typename scalar_t, int KV, int D, int NW>
+int launch_attn_nw(const AttnParams& p, int num_seqs, int num_partitions, hipStream_t stream) {
   const size_t smem = (size_t)NW * 16 * (2 + D) * sizeof(float);
   dim3 grid(p.num_kv_heads * p.q_tiles, num_seqs, num_partitions);
   auto kern = paged_attention_kernel<scalar_t, KV, D, NW>;
@@ -572,6 +572,20 @@ int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream
   kern<<<grid, dim3(NW * 64), smem, stream>>>(p);
   NMX_LAUNCH_CHECK();
   return NMX_OK;
+}
+
+template <typename scalar_t, int KV, int D>
+int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream_t stream) {
+  // Few workgroups (small batch: batch 1 x 8 kv heads x 2 partitions = 16): a CU streams its partition at its own
+  // per-CU rate whatever the rest of the chip does, so give every workgroup 8 waves (2 tiles of 32 tokens each at a
+  // 512-token partition, all K / V requests of the partition in flight at once) instead of 4.
+  if constexpr (D <= 128) {
+    const long wgs = (long)p.num_kv_heads * p.q_tiles * num_seqs * num_partitions;
+    int nw = wgs <= 128 ? 8 : 4;
+    if (const char* e = getenv("NMX_ATTN_NW")) nw = atoi(e) == 8 ? 8 : 4;  // sweeps / tests
+    if (nw == 8) return launch_attn_nw<scalar_t, KV, D, 8>(p, num_seqs, num_partitions, stream);
+  }
+  return launch_attn_nw<scalar_t, KV, D, 4>(p, num_seqs, num_partitions, stream);
 }
 
 template <typename scalar_t, int KV>
