@@ -45,6 +45,10 @@ VARIANTS = {
                 metric="decode tokens/sec, Llama-3-8B fp8 weights + fp8 KV TP=1",
                 workload="Llama-3-8B fp8 W8A8 (dynamic per-tensor activation quant + scaled_mm) + fp8-e4m3 KV decode step, "
                          "TP=1 (configs[3])"),
+    "gptq-exllama": dict(model=LLAMA3_8B, kv="auto",
+                         metric="decode tokens/sec, Llama-3-8B GPTQ-int4 through gptq_gemm (exllama format) TP=1",
+                         workload="Llama-3-8B GPTQ-int4 g128 decode step through gptq_gemm after gptq_shuffle - the one quantized "
+                                  "GEMM the reference itself builds for ROCm (CMakeLists.txt:149); same model as configs[1]"),
     "awq70b-tp8rank": dict(model=LLAMA3_70B_TP8_RANK, kv="auto",
                            metric="decode tokens/sec of ONE TP=8 rank, Llama-3-70B AWQ-int4 (no all-reduce in the timed step)",
                            workload="Llama-3-70B AWQ-int4 g128, the per-rank shard of TP=8 (configs[4]): compute of one rank, "
@@ -90,6 +94,10 @@ def random_weight(variant, K, N, group, device, gen):
         # [N, K] row-major fp8 weight, used as its column-major [K, N] transpose view (fp8.py:349-359)
         w = (torch.randn(N, K, device=device, generator=gen, dtype=torch.float16) * 0.02).to(torch.float8_e4m3fn)
         return w.t(), torch.full((1, ), 0.01, dtype=torch.float32, device=device)
+    if variant == "gptq-exllama":
+        q = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=device, generator=gen)
+        z = torch.randint(-2**31, 2**31 - 1, (K // group, N // 8), dtype=torch.int32, device=device, generator=gen)
+        return q, z, s, torch.empty(0, dtype=torch.int32, device=device)  # no act-order: empty g_idx (gptq.py:207-213)
     if variant == "awq70b-tp8rank":
         q = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int32, device=device, generator=gen)
         z = torch.randint(-2**31, 2**31 - 1, (K // group, N // 8), dtype=torch.int32, device=device, generator=gen)
@@ -115,6 +123,8 @@ class Llama3Decode:
             lw = {}
             for name, (K, N) in self.shapes.items():
                 lw[name] = random_weight(variant, K, N, cfg["group"], device, g)
+                if variant == "gptq-exllama":
+                    ops.gptq_shuffle(lw[name][0], lw[name][3], 4)  # exllama state machine, first apply (gptq.py:207-219)
             lw["ln1"] = torch.ones(H, dtype=torch.float16, device=device)
             lw["ln2"] = torch.ones(H, dtype=torch.float16, device=device)
             self.layers.append(lw)
@@ -170,6 +180,8 @@ class Llama3Decode:
             # Fp8LinearMethod.apply (fp8.py:340-359): dynamic per-tensor activation scale, then the scaled matmul
             qx, sx = ops.scaled_fp8_quant(x)
             return ops.cutlass_scaled_mm(qx, w[0], sx, w[1], torch.float16)
+        if self.variant == "gptq-exllama":  # GPTQLinearMethod.apply (gptq.py:198-231); weights shuffled once at load
+            return ops.gptq_gemm(x, w[0], w[1], w[2], w[3], True, 4)
         # AWQLinearMethod.apply (awq.py:166-172)
         return ops.awq_gemm(x, w[0], w[2], w[1], 8)
 
@@ -229,7 +241,7 @@ def gemm_bytes(M, K, N, group, variant="int4"):
         return K * N // 4 + K * N // 8 + scales + act       # kept values + 2-bit positions
     if variant == "fp8":
         return K * N + M * K + 2 * M * N                      # fp8 weights, fp8 activations
-    if variant == "awq70b-tp8rank":
+    if variant in ("awq70b-tp8rank", "gptq-exllama"):
         return K * N // 2 + scales + (K // group) * N // 2 + act  # + packed zero points
     return K * N // 2 + scales + act
 
@@ -433,6 +445,7 @@ def main():
         gemm_kernels = {"int4": ("marlin_gemm_kernel", "marlin_decode_kernel", "splitk_reduce_kernel"),
                         "sparse24": ("marlin_gemm_kernel", "splitk_reduce_kernel"),
                         "fp8": ("scaled_mm_kernel", ),
+                        "gptq-exllama": ("gptq_gemm_kernel", "splitk_reduce_kernel"),
                         "awq70b-tp8rank": ("awq_gemm_kernel", "splitk_reduce_kernel")}[args.config]
         att = [v for k, v in kb.items() if k.startswith("paged_attention")][0]
         gem_ms = sum(v["ms"] for v in gem)

@@ -10,6 +10,8 @@
 //  * AWQ   qweight [K, N/8]: one int32 = 8 columns of one k. A lane gathers the 8 k-rows of its 8-column chunk (8 dword
 //          loads), converts nibble PAIRS (two columns at once) and transposes pairs of k with v_perm_b32.
 // Workgroup = 4 waves splitting K (LDS reduce); grid.y splits K further (fp32 partial slabs + reduce kernel).
+#include <stdlib.h>
+
 #include "nmx_common.h"
 
 namespace {
@@ -295,6 +297,140 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(const ZpParams p) {
   }
 }
 
+// ---- GPTQ 4-bit, plain groups (no act-order gather, group % 128 == 0, K % 128 == 0): the decode path ------------------
+// Same arithmetic and operand order as gptq_gemm_kernel, but the loop above requests a k-step's operands and uses them
+// at once - every iteration pays a full memory round trip (32 us for gate_up at M = 1). Here a wave keeps two 128-k
+// units (4 weight loads + 4 MT activation loads + zero word + scale quad each) in flight: compiler-visible buffer loads
+// in one fixed order (prologue = loop order, branch-free pair loop, an odd last unit dropped through a zero scale), the
+// same scheme as marlin_decode_kernel. grid (N / 64, k_splits, ceil(M / (16 MT))), 4 waves = 4 K slices.
+template <int MT, bool SHUFFLED>
+__global__ __launch_bounds__(256, 2) void gptq_gemm_ring_kernel(const ZpParams p) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int n0 = blockIdx.x * 64;
+  const int nl = n0 + 4 * li;  // first of this lane's 4 columns
+  const int m0 = blockIdx.z * 16 * MT;
+  const int N = p.N, K = p.K;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int units = K / 128;
+  const int workers = p.k_splits * 4;
+  const int per = (units + workers - 1) / workers;
+  const int u0 = min(((int)blockIdx.y * 4 + wave) * per, units), u1 = min(u0 + per, units);
+  const int groups = K / p.G;
+
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.qweight), 0, (K / 8) * N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a), 0, p.M * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.qzeros), 0, groups * (N / 8) * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.scales), 0, groups * N * 2, 0x00020000);
+  const int q_voff = (g * N + nl) * 4;  // packed row 4 ks + g of the unit's 16, this lane's 4 columns
+  int a_voff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + li;
+    a_voff[mt] = m < p.M ? (m * K + 8 * g) * 2 : (int)0x7ff00000;  // beyond the descriptor: zeros
+  }
+  const int z_voff = (nl / 8) * 4, s_voff = nl * 2;
+
+  struct Unit { u32x4 q[4]; u32x4 a[4][MT]; uint32_t z; u32x2 s; };
+  auto load_step = [&](int u, int ks, Unit& U) {
+    u = min(u, units - 1);  // past the slice: the last unit again (never used)
+    U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_voff, (u * 16 + 4 * ks) * N * 4, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) U.a[ks][mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], (u * 128 + 32 * ks) * 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_group = [&](int u, Unit& U) {
+    u = min(u, units - 1);
+    const int grp = (u * 128) / p.G;
+    U.z = __builtin_amdgcn_raw_buffer_load_b32(rs_z, z_voff, grp * (N / 8) * 4, 0);
+    U.s = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, grp * N * 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_unit = [&](int u, Unit& U) {
+    load_group(u, U);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) load_step(u, ks, U);
+  };
+  const uint32_t MAGIC = 0x64006400u;
+  auto compute_unit = [&](Unit& U, int next, bool keep) {
+    // qzeros: this lane's 4 columns share one word (4 li % 8 = 0 or 4); stored value is z - 1 (q_gemm.cu:1408)
+    const uint32_t zw = U.z >> (4 * (nl & 7));
+    union { u32x2 u; f16 h[4]; } su;
+    su.u = U.s;
+    load_group(next, U);
+    uint32_t zmag[4], sc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t z = ((zw >> (4 * t)) & 0xf) + 1;
+      zmag[t] = 0x64006400u + z * 0x00010001u;
+      union { f16 h[2]; uint32_t u; } pk;
+      pk.h[0] = su.h[t];
+      pk.h[1] = su.h[t];
+      sc[t] = keep ? pk.u : 0u;  // a dropped unit contributes (q - z) * 0
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 af[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        af[mt] = U.a[ks][mt];
+        if constexpr (!SHUFFLED) {
+          const u32x4 a = af[mt];
+          af[mt][0] = __builtin_amdgcn_perm(a[2], a[0], 0x05040100u);  // (k0, k4)
+          af[mt][1] = __builtin_amdgcn_perm(a[2], a[0], 0x07060302u);  // (k1, k5)
+          af[mt][2] = __builtin_amdgcn_perm(a[3], a[1], 0x05040100u);  // (k2, k6)
+          af[mt][3] = __builtin_amdgcn_perm(a[3], a[1], 0x07060302u);  // (k3, k7)
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t q = U.q[ks][t];
+        u32x4 wf;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wf[d] = u32((h2(and_or(q >> (4 * d), 0x000f000fu, MAGIC)) - h2(zmag[t])) * h2(sc[t]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][t] = mfma_f16(wf, af[mt], acc[mt][t]);
+      }
+      load_step(next, ks, U);
+    }
+  };
+  if (u0 < u1) {
+    Unit ua, ub;
+    load_unit(u0, ua);
+    load_unit(u0 + 1, ub);
+    for (int u = u0; u < u1; u += 2) {
+      compute_unit(ua, u + 2, true);
+      compute_unit(ub, u + 3, u + 1 < u1);
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  reduce_waves<MT, 4>(acc, smem, wave, lane);
+  if (wave != 0) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * (4 * g + r);
+      if (n >= N) continue;
+      if (p.k_splits == 1) {
+        union { f16 h[4]; u32x2 u; } o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o.h[t] = (f16)acc[mt][t][r];
+        *reinterpret_cast<u32x2*>(p.c + (int64_t)m * N + n) = o.u;
+      } else {
+        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * p.M + m) * N + n) =
+            f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+      }
+    }
+  }
+}
+
 // ---- GPTQ 2 / 3 / 8-bit (gptq/q_gemm.cu:329-700 gemm kernels, :1386-1470 reconstruct) ------------------------------
 // Legacy bit widths, kept simple: weights stay in the checkpoint's sequential packing (element k of a column is a
 // BITS-wide field of a contiguous bit stream over k: 16 / 4 per word for 2 / 8 bit, 32 per 3 words for 3 bit; qzeros
@@ -538,6 +674,21 @@ extern "C" int nmx_gptq_gemm(const void* a, const int32_t* qweight, const int32_
     else NMX_GPTQ_BITS(8);
 #undef NMX_GPTQ_BITS
 #undef NMX_GPTQ_B
+    NMX_LAUNCH_CHECK();
+    if (p.k_splits > 1) {
+      const int64_t mn4 = (int64_t)m * n / 4;
+      zp_reduce_kernel<<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>((f16*)c, p.partial, mn4, p.k_splits);
+      NMX_LAUNCH_CHECK();
+    }
+    return NMX_OK;
+  }
+  if (!gather && !per_row && G % 128 == 0 && k % 128 == 0 && (int64_t)k * n / 2 < (1ll << 31) && (int64_t)m * k * 2 < (1ll << 31) &&
+      getenv("NMX_GPTQ_NO_RING") == nullptr) {
+    // keep >= 2 units (256 k) per wave so that the ring has something to overlap
+    while (p.k_splits > 1 && (k / 128) / (p.k_splits * 4) < 2) p.k_splits /= 2;
+    grid.y = p.k_splits;
+    if (use_exllama) { if (mt == 1) gptq_gemm_ring_kernel<1, true><<<grid, 256, smem, stream>>>(p); else gptq_gemm_ring_kernel<2, true><<<grid, 256, smem, stream>>>(p); }
+    else { if (mt == 1) gptq_gemm_ring_kernel<1, false><<<grid, 256, smem, stream>>>(p); else gptq_gemm_ring_kernel<2, false><<<grid, 256, smem, stream>>>(p); }
     NMX_LAUNCH_CHECK();
     if (p.k_splits > 1) {
       const int64_t mn4 = (int64_t)m * n / 4;
