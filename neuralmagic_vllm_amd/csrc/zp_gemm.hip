@@ -167,6 +167,125 @@ __global__ __launch_bounds__(256) void awq_gemm_kernel(const ZpParams p) {
   }
 }
 
+// ---- AWQ, group % 128 == 0 and K % 128 == 0: same arithmetic as awq_gemm_kernel with two 128-k units of operands in
+// flight per wave (see gptq_gemm_ring_kernel). grid (N / 128, k_splits, ceil(M / (16 MT))).
+template <int MT>
+__global__ __launch_bounds__(256, 2) void awq_gemm_ring_kernel(const ZpParams p) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int NC = p.N / 8, K = p.K;
+  const int c = blockIdx.x * 16 + li;  // this lane's 8-column chunk
+  const int cc = c < NC ? c : 0;
+  const int m0 = blockIdx.z * 16 * MT;
+  f32x4 acc[MT][8];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int units = K / 128;
+  const int workers = p.k_splits * 4;
+  const int per = (units + workers - 1) / workers;
+  const int u0 = min(((int)blockIdx.y * 4 + wave) * per, units), u1 = min(u0 + per, units);
+  const int groups = K / p.G;
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.qweight), 0, K * NC * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a), 0, p.M * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.qzeros), 0, groups * NC * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.scales), 0, groups * p.N * 2, 0x00020000);
+  const int q_voff = (8 * g * NC + cc) * 4;  // k-row 8 g (+ jj through the scalar offset) of the 32-k step, this lane's chunk
+  int a_voff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + li;
+    a_voff[mt] = m < p.M ? (m * K + 8 * g) * 2 : (int)0x7ff00000;
+  }
+  struct Unit { uint32_t r[4][8]; u32x4 a[4][MT]; uint32_t z; u32x4 s; };
+  auto load_step = [&](int u, int ks, Unit& U) {
+    u = min(u, units - 1);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) U.r[ks][jj] = __builtin_amdgcn_raw_buffer_load_b32(rs_q, q_voff, (u * 128 + 32 * ks + jj) * NC * 4, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) U.a[ks][mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], (u * 128 + 32 * ks) * 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_group = [&](int u, Unit& U) {
+    u = min(u, units - 1);
+    const int grp = (u * 128) / p.G;
+    U.z = __builtin_amdgcn_raw_buffer_load_b32(rs_z, cc * 4, grp * NC * 4, 0);
+    U.s = __builtin_amdgcn_raw_buffer_load_b128(rs_s, cc * 16, grp * p.N * 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_unit = [&](int u, Unit& U) {
+    load_group(u, U);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) load_step(u, ks, U);
+  };
+  const uint32_t MAGIC = 0x64006400u;
+  auto compute_unit = [&](Unit& U, int next, bool keep) {
+    const uint32_t z = U.z;
+    const u32x4 sv = U.s;
+    load_group(next, U);
+    uint32_t zmag[4], sc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      zmag[d] = and_or(z >> (4 * d), 0x000f000fu, MAGIC);  // (1024 + z_2d, 1024 + z_2d+1): nibbles d and d + 4
+      sc[d] = keep ? sv[d] : 0u;                            // (s_2d, s_2d+1); a dropped unit contributes (q - z) * 0
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint32_t x[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) x[jj] = u32((h2(and_or(U.r[ks][jj] >> (4 * d), 0x000f000fu, MAGIC)) - h2(zmag[d])) * h2(sc[d]));
+        u32x4 w_lo, w_hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          w_lo[q] = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x05040100u);
+          w_hi[q] = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x07060302u);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][2 * d] = mfma_f16(w_lo, U.a[ks][mt], acc[mt][2 * d]);
+          acc[mt][2 * d + 1] = mfma_f16(w_hi, U.a[ks][mt], acc[mt][2 * d + 1]);
+        }
+      }
+      load_step(next, ks, U);
+    }
+  };
+  if (u0 < u1) {
+    Unit ua, ub;
+    load_unit(u0, ua);
+    load_unit(u0 + 1, ub);
+    for (int u = u0; u < u1; u += 2) {
+      compute_unit(ua, u + 2, true);
+      compute_unit(ub, u + 3, u + 1 < u1);
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  reduce_waves<MT, 8>(acc, smem, wave, lane);
+  if (wave != 0) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int chunk = blockIdx.x * 16 + 4 * g + r;
+      if (chunk >= NC) continue;
+      if (p.k_splits == 1) {
+        union { f16 h[8]; u32x4 u; } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.h[e] = (f16)acc[mt][e][r];
+        *reinterpret_cast<u32x4*>(p.c + (int64_t)m * p.N + 8 * chunk) = o.u;
+      } else {
+        float* dst = p.partial + ((int64_t)blockIdx.y * p.M + m) * p.N + 8 * chunk;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[mt][4][r], acc[mt][5][r], acc[mt][6][r], acc[mt][7][r]};
+      }
+    }
+  }
+}
+
 // awq_dequantize (awq/gemm_kernels.cu:367-431): one thread per packed word -> 8 fp16
 __global__ void awq_dequantize_kernel(const uint32_t* __restrict__ qweight, const f16* __restrict__ scales,
                                       const uint32_t* __restrict__ qzeros, f16* __restrict__ out, int K, int NC, int G) {
@@ -613,7 +732,14 @@ extern "C" int nmx_awq_gemm(const void* in_feats, const int32_t* kernel, const v
   if (p.k_splits > 1 && (scratch == nullptr || scratch_bytes < (int64_t)p.k_splits * m * oc * 4))
     p.k_splits = scratch ? std::max<int>(1, (int)(scratch_bytes / ((int64_t)m * oc * 4))) : 1;
   dim3 grid(n_tiles, p.k_splits, m_blocks);
-  if (mt == 1) awq_gemm_kernel<1><<<grid, 256, 3 * 1 * 8 * 64 * 16, stream>>>(p);
+  const bool ring = group_size % 128 == 0 && k % 128 == 0 && (int64_t)k * oc / 2 < (1ll << 31) && (int64_t)m * k * 2 < (1ll << 31) &&
+                    getenv("NMX_AWQ_NO_RING") == nullptr;
+  if (ring) {
+    while (p.k_splits > 1 && (k / 128) / (p.k_splits * 4) < 1) p.k_splits /= 2;  // >= 1 unit per wave (tiny N: CUs first)
+    grid.y = p.k_splits;
+    if (mt == 1) awq_gemm_ring_kernel<1><<<grid, 256, 3 * 1 * 8 * 64 * 16, stream>>>(p);
+    else awq_gemm_ring_kernel<2><<<grid, 256, 3 * 2 * 8 * 64 * 16, stream>>>(p);
+  } else if (mt == 1) awq_gemm_kernel<1><<<grid, 256, 3 * 1 * 8 * 64 * 16, stream>>>(p);
   else awq_gemm_kernel<2><<<grid, 256, 3 * 2 * 8 * 64 * 16, stream>>>(p);
   NMX_LAUNCH_CHECK();
   if (p.k_splits > 1) {
