@@ -1388,7 +1388,7 @@ GemmCfg pick_cfg(int M, int N, int K) {
     const int got = sscanf(e, "%d,%d,%d,%d", &a, &b, &s, &w);
     const bool w8 = got == 4 && w != 0 && a == 4;
     if (got >= 3 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && s >= 1 &&
-        !(a == 4 && b != 4 && !(w8 && b == 2)) && !(a == 2 && b == 1)) {
+        !(a == 4 && b == 1) && !(a == 2 && b == 1)) {
       c.mt = a; c.ng = b; c.splits = s;
       c.w8 = w8 ? 1 : 0;
       return c;
@@ -1454,6 +1454,7 @@ int launch_mode(const GemmParams& p, const GemmCfg& cfg, hipStream_t stream) {
   if (cfg.mt == 1) return launch_cfg<scalar_t, KIND, 1, 4, MODE, SP>(p, stream);
   if (cfg.mt == 2 && cfg.ng == 4) return launch_cfg<scalar_t, KIND, 2, 4, MODE, SP>(p, stream);
   if (cfg.mt == 2) return launch_cfg<scalar_t, KIND, 2, 2, MODE, SP>(p, stream);
+  if (cfg.mt == 4 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 4, 2, MODE, SP>(p, stream);
   return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP>(p, stream);
 }
 
