@@ -61,7 +61,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="sequences decoded per step and per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="sequences decoded per step and per GPU (SURVEY 8d sweeps 1..256; "
+                    "the headline is the largest: serving throughput, and the regime the north star's MFMA target for the linear "
+                    "layers refers to)")
     ap.add_argument("--ctx", type=int, default=1024, help="KV context length of every sequence")
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--config", choices=sorted(VARIANTS), default="int4", help="which BASELINE.json config to run")
@@ -316,7 +318,7 @@ def cpu_baseline(cfg, batch, ctx):
     torch.manual_seed(0)
     H, I, nh, nkv, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head"]
     shapes = [(H, (nh + 2 * nkv) * D), (nh * D, H), (H, 2 * I), (I, H)]
-    cpu_batch = min(batch, 64)
+    cpu_batch = min(batch, 256)
     gemm_in = []
     for K, N in shapes:
         mq = torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32)
@@ -362,7 +364,7 @@ def pmc_traffic(kernels, args):
         return None, None
     try:
         prof = json.load(open(files[-1]))
-        meta = prof.get("_workload", {"batch": 64, "ctx": 1024})
+        meta = prof.get("_workload", {"batch": 256, "ctx": 1024})
         if meta.get("batch") != args.batch or meta.get("ctx") != args.ctx or args.config != meta.get("config", "int4"):
             return None, None
         # bytes of all the class's kernels (main kernel(s) + split-K reduce where one ran) per call of the op:
