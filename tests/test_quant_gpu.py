@@ -60,7 +60,8 @@ def to_int8(t):
     return torch.round(t.clamp(min=-128, max=127)).to(dtype=torch.int8)
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 16, 16), (1, 4096, 4096), (16, 6144, 4096), (33, 256, 496), (64, 1024, 128), (83, 512, 1024), (512, 512, 512)])
+@pytest.mark.parametrize("m,n,k", [(1, 16, 16), (1, 4096, 4096), (16, 6144, 4096), (33, 256, 496), (64, 1024, 128), (83, 512, 1024), (512, 512, 512),
+                                   (100, 80, 14336), (64, 4096, 14336), (5, 144, 256), (17, 64, 64)])
 @pytest.mark.parametrize("per_act_token", [True, False])
 @pytest.mark.parametrize("per_out_ch", [True, False])
 @pytest.mark.parametrize("is_fp8", [True, False])
