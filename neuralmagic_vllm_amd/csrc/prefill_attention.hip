@@ -15,6 +15,9 @@
 //
 // Compute-bound: 4 * (ctx + (i + 1)) * D flop per (query token, head); algorithmic bytes = q + out + the KV it reads.
 #include <float.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "nmx_common.h"
 
@@ -69,13 +72,15 @@ __device__ __forceinline__ u32x4 p_to_operand(u32x2 a, u32x2 b) {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <typename scalar_t, int D>
+// GQ = query heads of one kv head processed by a wave (1 or 2): the K / V fragments of a tile are loaded once and
+// feed GQ x as many MFMAs - the kernel is bound by the wave-instruction rate of its operand loads, not by the MFMAs.
+template <typename scalar_t, int D, int GQ>
 __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillParams p) {
   constexpr int KS = (D + 31) / 32;
   constexpr int NT = D / 16;
   constexpr int CHUNKS = D / 8;
   constexpr int VROW = D * 2 + 16;  // bytes per staged V row (+16: rows start on different banks)
-  const int b = blockIdx.z, head = blockIdx.y;
+  const int b = blockIdx.z, head0 = blockIdx.y * GQ;  // heads head0 .. head0 + GQ - 1 share one kv head
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
@@ -84,11 +89,13 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
   const int start = p.b_start_loc[b];
   const int r0 = (blockIdx.x * 4 + wave) * 16;
   if (r0 >= q_len) return;  // whole wave: EXEC stays full for the transposing reads of the active waves
-  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  const int kvh = head0 / (p.num_heads / p.num_kv_heads);
   const int row = r0 + li;
   const bool row_ok = row < q_len;
   const int qpos = ctx + row;
-  const float slope = p.alibi_slopes != nullptr ? p.alibi_slopes[head] : 0.f;
+  float slope[GQ];
+#pragma unroll
+  for (int h = 0; h < GQ; ++h) slope[h] = p.alibi_slopes != nullptr ? p.alibi_slopes[head0 + h] : 0.f;
   const bool has_alibi = p.alibi_slopes != nullptr;
   const int W = p.sliding_window;
 
@@ -96,25 +103,36 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
   char* vs = smem + (size_t)wave * 32 * VROW;  // this wave's [32 tokens][D] tile
 
   const scalar_t* Q = reinterpret_cast<const scalar_t*>(p.q);
-  u32x4 qf[KS];
-  {
-    const scalar_t* qp = Q + (int64_t)(start + min(row, q_len - 1)) * p.q_st + (int64_t)head * p.q_sh;
+  u32x4 qf[GQ][KS];
+#pragma unroll
+  for (int h = 0; h < GQ; ++h) {
+    const scalar_t* qp = Q + (int64_t)(start + min(row, q_len - 1)) * p.q_st + (int64_t)(head0 + h) * p.q_sh;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int chunk = 4 * ks + g;
       u32x4 val = {0, 0, 0, 0};
       if (chunk < CHUNKS) val = *reinterpret_cast<const u32x4*>(qp + chunk * 8);
-      qf[ks] = val;
+      qf[h][ks] = val;
     }
   }
 
-  float m_run = -FLT_MAX, l_part = 0.f;
-  f32x4 o[NT];
+  float m_runs[GQ], l_parts[GQ];
+  f32x4 os[GQ][NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < GQ; ++h) {
+    m_runs[h] = -FLT_MAX;
+    l_parts[h] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) os[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  // one 32-token tile: logits s (already K.Q^T), key positions kpos0 + 16u + 4g + r, V fragments vf
-  auto softmax_pv = [&](f32x4 (&s)[2], int kpos0, int limit, bool causal, const u32x4 (&vf)[NT]) {
+  // one 32-token tile of head h: logits s (already K.Q^T), key positions kpos0 + 16u + 4g + r, V fragments vf
+  auto softmax_pv = [&](auto hc, f32x4 (&s)[2], int kpos0, int limit, bool causal, const u32x4 (&vf)[NT]) {
+    constexpr int h = decltype(hc)::value;
+    float& m_run = m_runs[h];
+    float& l_part = l_parts[h];
+    f32x4 (&o)[NT] = os[h];
+    const float slope_h = slope[h];
     bool msk[2][4];
     float m_tile = -FLT_MAX;
 #pragma unroll
@@ -124,7 +142,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
         const int kpos = kpos0 + 16 * u + 4 * g + r;
         float val = s[u][r] * p.scale;
         if (W > 0 && qpos - kpos >= W) val = -10000.f;  // prefix_prefill.py:88-104, :201-204
-        if (has_alibi) val += slope * (float)(kpos - qpos);  // :552-557
+        if (has_alibi) val += slope_h * (float)(kpos - qpos);  // :552-557
         const bool masked = kpos >= limit || (causal && kpos > qpos) || !row_ok;
         msk[u][r] = masked;
         s[u][r] = val;
@@ -207,15 +225,18 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
           vf[nt] = val;
         }
       }
-      f32x4 s[2];
+      f32x4 s[GQ][2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < GQ; ++h)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s[u] = mfma<scalar_t>(kf[u][ks], qf[ks], s[u]);
-      }
+        for (int u = 0; u < 2; ++u) {
+          s[h][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) s[h][u] = mfma<scalar_t>(kf[u][ks], qf[h][ks], s[h][u]);
+        }
       if (more) load_k(t0 + 32, kf, vphys);  // into the registers the MFMAs above have just consumed
-      softmax_pv(s, t0, ctx, false, vf);
+      softmax_pv(std::integral_constant<int, 0>{}, s[0], t0, ctx, false, vf);
+      if constexpr (GQ > 1) softmax_pv(std::integral_constant<int, GQ - 1>{}, s[GQ - 1], t0, ctx, false, vf);
     }
   }
 
@@ -257,13 +278,15 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
         const int piece = it * 64 + lane;
         *reinterpret_cast<u32x4*>(vs + (piece / CHUNKS) * VROW + (piece % CHUNKS) * 16) = vr[it];
       }
-      f32x4 s[2];
+      f32x4 s[GQ][2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < GQ; ++h)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s[u] = mfma<scalar_t>(kf[u][ks], qf[ks], s[u]);
-      }
+        for (int u = 0; u < 2; ++u) {
+          s[h][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) s[h][u] = mfma<scalar_t>(kf[u][ks], qf[h][ks], s[h][u]);
+        }
       if (more) load_kv(t0 + 32, kf, vr);  // into the registers the LDS writes and MFMAs above have just consumed
       __builtin_amdgcn_wave_barrier();  // the tile above is this wave's own; LDS operations of a wave stay in order
       // V^T fragments: lane i of a 16-lane group supplies the address of row (i >> 2), columns 4 (i & 3) .. + 3 of a
@@ -281,34 +304,51 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
           vf[nt] = u32x4{l2[0], l2[1], h2[0], h2[1]};
         }
       }
-      softmax_pv(s, ctx + t0, ctx + q_len, true, vf);
+      softmax_pv(std::integral_constant<int, 0>{}, s[0], ctx + t0, ctx + q_len, true, vf);
+      if constexpr (GQ > 1) softmax_pv(std::integral_constant<int, GQ - 1>{}, s[GQ - 1], ctx + t0, ctx + q_len, true, vf);
       __builtin_amdgcn_wave_barrier();
     }
   }
 
   // ---- out[row][d] = O / l ; lane (g, q) holds O^T[16 nt + 4 g + r][q] ----
-  l_part += __shfl_xor(l_part, 16, 64);
-  l_part += __shfl_xor(l_part, 32, 64);
-  if (!row_ok) return;
-  const float inv = 1.f / l_part;
-  scalar_t* op = reinterpret_cast<scalar_t*>(p.out) + (int64_t)(start + row) * p.o_st + (int64_t)head * p.o_sh;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    union { scalar_t h[4]; u32x2 u; } r;
+  for (int h = 0; h < GQ; ++h) {
+    float l_part = l_parts[h];
+    l_part += __shfl_xor(l_part, 16, 64);
+    l_part += __shfl_xor(l_part, 32, 64);
+    if (!row_ok) continue;
+    const float inv = 1.f / l_part;
+    scalar_t* op = reinterpret_cast<scalar_t*>(p.out) + (int64_t)(start + row) * p.o_st + (int64_t)(head0 + h) * p.o_sh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(o[nt][j] * inv);
-    *reinterpret_cast<u32x2*>(op + 16 * nt + 4 * g) = r.u;
+    for (int nt = 0; nt < NT; ++nt) {
+      union { scalar_t e[4]; u32x2 u; } r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r.e[j] = Scalar<scalar_t>::from_f32(os[h][nt][j] * inv);
+      *reinterpret_cast<u32x2*>(op + 16 * nt + 4 * g) = r.u;
+    }
   }
 }
 
 template <typename scalar_t, int D>
 int launch(const PrefillParams& p, int batch, int max_input_len, hipStream_t stream) {
   const size_t smem = (size_t)4 * 32 * (D * 2 + 16);
-  dim3 grid(ceil_div(max_input_len, 64), p.num_heads, batch);
-  auto kern = prefill_attention_kernel<scalar_t, D>;
-  if (smem > 64 * 1024)
-    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  kern<<<grid, 256, smem, stream>>>(p);
+  // two query heads per wave when the GQA group allows it (and the wider heads' accumulators still fit)
+  // (measured, Llama-3-8B heads: +17-20 % on 1-4 K-token prefills, equal at 512 new + 512 cached tokens; with 16 new
+  // tokens per sequence only one wave of a workgroup is active and the second head's registers just cost occupancy)
+  bool gq2 = D <= 128 && (p.num_heads / p.num_kv_heads) % 2 == 0 && max_input_len >= 256;
+  if (const char* e = getenv("NMX_PREFILL_GQ")) gq2 = gq2 && atoi(e) == 2;
+  dim3 grid(ceil_div(max_input_len, 64), gq2 ? p.num_heads / 2 : p.num_heads, batch);
+  if (gq2) {
+    if constexpr (D <= 128) {
+      auto kern = prefill_attention_kernel<scalar_t, D, 2>;
+      kern<<<grid, 256, smem, stream>>>(p);
+    }
+  } else {
+    auto kern = prefill_attention_kernel<scalar_t, D, 1>;
+    if (smem > 64 * 1024)
+      NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    kern<<<grid, 256, smem, stream>>>(p);
+  }
   NMX_LAUNCH_CHECK();
   return NMX_OK;
 }
