@@ -335,8 +335,9 @@ int launch(const PrefillParams& p, int batch, int max_input_len, hipStream_t str
   // two query heads per wave when the GQA group allows it (and the wider heads' accumulators still fit)
   // (measured, Llama-3-8B heads: +17-20 % on 1-4 K-token prefills, equal at 512 new + 512 cached tokens; with 16 new
   // tokens per sequence only one wave of a workgroup is active and the second head's registers just cost occupancy)
-  bool gq2 = D <= 128 && (p.num_heads / p.num_kv_heads) % 2 == 0 && max_input_len >= 256;
-  if (const char* e = getenv("NMX_PREFILL_GQ")) gq2 = gq2 && atoi(e) == 2;
+  const bool gq2_ok = D <= 128 && (p.num_heads / p.num_kv_heads) % 2 == 0;
+  bool gq2 = gq2_ok && max_input_len >= 256;
+  if (const char* e = getenv("NMX_PREFILL_GQ")) gq2 = gq2_ok && atoi(e) == 2;  // tests / sweeps: force either shape
   dim3 grid(ceil_div(max_input_len, 64), gq2 ? p.num_heads / 2 : p.num_heads, batch);
   if (gq2) {
     if constexpr (D <= 128) {
