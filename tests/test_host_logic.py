@@ -116,3 +116,26 @@ def test_packers_round_trip_every_bit_width():
         assert qw.shape == (128 * bits // 32, 64) and qz.shape == (4, 64 * bits // 32)
         assert torch.equal(oracle.gptq_dequantize(qw, qz, s, None, bits), w_ref)
         assert torch.equal(oracle.gptq_dequantize(qw, qz, s, g_idx, bits), w_ref)
+
+
+def test_split_plan_of_the_llama_shapes_is_stable():
+    """Host-only view of the launch heuristics through the scratch-size query (no GPU): the K splits chosen for the shapes
+    the heuristics were fitted on, so that a change of plan shows up in review instead of in a benchmark."""
+    import ctypes
+
+    from neuralmagic_vllm_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.nmx_marlin_gemm_scratch_bytes.restype = ctypes.c_int64
+    lib.nmx_scaled_mm_scratch_bytes.restype = ctypes.c_int64
+
+    def splits(fn, m, n, k):
+        return fn(m, n, k) // (m * n * 4)
+
+    gm, mm = lib.nmx_marlin_gemm_scratch_bytes, lib.nmx_scaled_mm_scratch_bytes
+    # (K, N): qkv, o, gate_up, down of Llama-3-8B
+    assert [splits(gm, 1, 6144, 4096), splits(gm, 64, 6144, 4096)] == [2, 2]
+    assert [splits(gm, 1, 4096, 4096), splits(gm, 64, 4096, 4096)] == [4, 4]
+    assert [splits(gm, 1, 28672, 4096), splits(gm, 64, 28672, 4096)] == [0, 0]   # gate_up: enough column tiles, no split
+    assert splits(gm, 64, 4096, 14336) == 8
+    assert gm(0, 4096, 4096) == 0 and mm(0, 4096, 4096) == 0
+    assert [splits(mm, 64, 6144, 4096), splits(mm, 64, 28672, 4096), splits(mm, 64, 4096, 14336)] == [2, 0, 4]
