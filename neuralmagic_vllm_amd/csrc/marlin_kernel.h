@@ -516,6 +516,24 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
         else gacc[ACC_SCALE ? mt : 0][t] = mfma_16x16x32<scalar_t>(wf, af[mt], gacc[ACC_SCALE ? mt : 0][t]);
       }
     }
+#ifndef NMX_SCHED_PIPE
+#define NMX_SCHED_PIPE 10  // VALU instructions ahead of the first MFMA of a k-step; 0 = leave the order to hipcc
+#endif
+#if NMX_SCHED_PIPE > 0
+    // (measured at M = 256: gate_up 84.0 -> 78.9 us, down 45.9 -> 44.5; no change at M <= 64)
+    // Ask the scheduler for the software pipeline the data flow allows inside one k-step: fragment reads first, the
+    // first tile's dequantisation, then one MFMA followed by the VALU work that fits in its 16-cycle shadow (the next
+    // tile's dequantisation), NTILE * MT times.
+    if constexpr (!GENERIC && MT >= 2) {
+      __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);       // DS reads: the activation fragments
+      __builtin_amdgcn_sched_group_barrier(0x002, NMX_SCHED_PIPE, 0);  // VALU: first tile
+#pragma unroll
+      for (int i = 0; i < NTILE * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three VALU in its shadow
+      }
+    }
+#endif
   };
   using GA0 = std::integral_constant<int, 0>;
   using GA1 = std::integral_constant<int, 1>;
