@@ -458,24 +458,27 @@ def main():
             "paged_attention_kernel": dict(ms=att["ms"], bytes=att["bytes"], flops=att["flops"],
                                            step_ms=att["ms"] * att["launches"], prof=("paged_attention_kernel", )),
         }
+        def roof_of(name):
+            d = classes[name]
+            d["gbs"] = d["bytes"] / d["ms"] / 1e6
+            d["tflops"] = d["flops"] / d["ms"] / 1e9
+            mfma_peak = MFMA_F16_PEAK_TF * (2.0 if (args.config == "fp8" and name != "paged_attention_kernel") else 1.0)  # fp8: 5 PF
+            # HBM-bound below the ridge (4*M flop/B vs ~312 flop/B machine balance)
+            hbm_bound = d["flops"] / d["bytes"] < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+            traffic, traffic_src = pmc_traffic(d["prof"], args)
+            common = dict(kernel=name, traffic=traffic, traffic_source=traffic_src, avg_launch_us=round(d["ms"] * 1e3, 2),
+                          step_share_ms=round(d["step_ms"], 3), kernels_in_launch=list(d["prof"]))
+            if hbm_bound:
+                return dict(bound="hbm", achieved=round(d["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(d["gbs"] / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=int(d["bytes"]), **common)
+            return dict(bound="mfma", achieved=round(d["tflops"], 1), peak=mfma_peak, unit="TFLOP/s",
+                        frac=round(d["tflops"] / mfma_peak, 4), algorithmic_flops_per_launch=float(d["flops"]), **common)
+
+        rooflines = {name: roof_of(name) for name in classes}
+        # the dominant kernel class of the step (at the default batch the GEMMs and the attention are within a few per
+        # cent of each other; `rooflines` below carries both)
         dom = max(classes, key=lambda k: classes[k]["step_ms"])
-        d = classes[dom]
-        d["gbs"] = d["bytes"] / d["ms"] / 1e6
-        d["tflops"] = d["flops"] / d["ms"] / 1e9
-        # HBM-bound below the ridge (4*M flop/B vs ~312 flop/B machine balance)
-        mfma_peak = MFMA_F16_PEAK_TF * (2.0 if (args.config == "fp8" and dom != "paged_attention_kernel") else 1.0)  # fp8: 5 PF
-        hbm_bound = d["flops"] / d["bytes"] < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-        traffic, traffic_src = pmc_traffic(d["prof"], args)
-        if hbm_bound:
-            roof = dict(bound="hbm", kernel=dom, achieved=round(d["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(d["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_bytes_per_launch=int(d["bytes"]),
-                        kernels_in_launch=list(d["prof"]))
-        else:
-            roof = dict(bound="mfma", kernel=dom, achieved=round(d["tflops"], 1), peak=mfma_peak, unit="TFLOP/s",
-                        frac=round(d["tflops"] / mfma_peak, 4), traffic=traffic, traffic_source=traffic_src,
-                        avg_launch_us=round(d["ms"] * 1e3, 2), algorithmic_flops_per_launch=float(d["flops"]),
-                        kernels_in_launch=list(d["prof"]))
+        roof = rooflines[dom]
         result = {
             "metric": var["metric"],
             "value": round(value, 1),
@@ -494,6 +497,7 @@ def main():
                        "kv_cache": ("fp8-e4m3" if model.kv_dtype == "fp8" else "fp16") + " block 16", "hip_graph": graph is not None,
                        "parallelism": f"dp{world} (independent TP=1 replicas)"},
             "roofline": roof,
+            "rooflines": rooflines,
             "kernels": {k: {"us": round(v["ms"] * 1e3, 2), "GBps": round(v["gbs"], 1), "TFLOPs": round(v["tflops"], 2),
                             "step_share_ms": round(per_step[k], 3)} for k, v in kb.items()},
             "hot_path_share_of_step": round(sum(per_step.values()) / ms_per_step, 3),
