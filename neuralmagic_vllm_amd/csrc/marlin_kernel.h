@@ -1412,6 +1412,12 @@ GemmCfg pick_cfg(int M, int N, int K) {
       return c;
     }
   }
+  if (c.w8 && c.ng == 4) {
+    // between one and two 8-wave workgroups per CU (gate_up at M = 256: 448) the second round runs three quarters
+    // empty; 4-wave workgroups are all resident at two per CU instead (79.3 vs 83.8 us)
+    const int u8 = ceil_div(N, 256) * ceil_div(M, 64);
+    if (u8 > 256 && u8 <= 512) c.w8 = 0;
+  }
   const int kw = (c.w8 ? 8 : 4) / c.ng;
   const int total_steps = ceil_div(K, 32);
   const int total_sub = ceil_div(total_steps, 4);

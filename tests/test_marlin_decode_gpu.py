@@ -99,3 +99,14 @@ def test_llama_shapes_default_dispatch(ops, force):
         for m in (1, 16, 32, 64):
             a = torch.randn(m, K, dtype=torch.float16)
             assert compute_max_diff(run(ops, a, q, s, K, N), a.float() @ w_ref) < TOL
+
+
+def test_wide_n_large_m_default_dispatch(ops, force):
+    """gate_up-sized N at M = 200 / 256: the 4-wave 256-column workgroups picked when 8-wave ones would leave a ragged
+    second round."""
+    force()
+    K, N = 1024, 28672
+    w_ref, q, s = make(K, N, 128, seed=5)
+    for m in (200, 256):
+        a = torch.randn(m, K, dtype=torch.float16)
+        assert compute_max_diff(run(ops, a, q, s, K, N), a.float() @ w_ref) < TOL
