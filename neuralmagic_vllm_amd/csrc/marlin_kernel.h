@@ -35,6 +35,12 @@ namespace {
 #define NMX_ABLATE 0
 #endif
 
+// Non-temporal hint on the weight loads of marlin_decode_kernel (every byte read once: +4-7 %; in marlin_gemm_kernel the
+// same hint measured 3-10 % SLOWER, with one row block too, and is not used there); 0 = plain loads
+#ifndef NMX_W_NT
+#define NMX_W_NT 1
+#endif
+
 constexpr int kSubSteps = 4;  // 32-k steps per activation staging sub-chunk (128 k)
 
 enum WeightKind { W_INT4 = 0, W_INT8 = 1, W_FP8 = 2 };
@@ -77,7 +83,6 @@ __device__ __forceinline__ void buf_load_x4(u32x4& dst, int voff, i32x4 rsrc, in
   soff = __builtin_amdgcn_readfirstlane(soff);
   asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
-
 __device__ __forceinline__ uint32_t h2_bits(f16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ f16x2 bits_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
 
@@ -1168,7 +1173,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
   // loads of one 32-k step / of the scale rows of unit u (past the slice: the last unit again, never consumed)
   auto load_step = [&](int u, int ks, Unit& U) {
     u = min(u, total_units - 1);
-    U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, (u * 8 + 2 * ks) * row_bytes, 0);
+    // aux 2 = non-temporal: the weights are read once (this kernel is used with one row block; a constant, because a
+    // branch around the load halves the wait counts hipcc can prove)
+    U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, (u * 8 + 2 * ks) * row_bytes, NMX_W_NT ? 2 : 0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       U.a[ks][mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], (u * 128 + ks * 32) * 2, 0);

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void gptq_gemm_kernel(const ZpParams p) {
 // units (4 weight loads + 4 MT activation loads + zero word + scale quad each) in flight: compiler-visible buffer loads
 // in one fixed order (prologue = loop order, branch-free pair loop, an odd last unit dropped through a zero scale), the
 // same scheme as marlin_decode_kernel. grid (N / 64, k_splits, ceil(M / (16 MT))), 4 waves = 4 K slices.
-template <int MT, bool SHUFFLED>
+template <int MT, bool SHUFFLED, bool NT>
 __global__ __launch_bounds__(256, 2) void gptq_gemm_ring_kernel(const ZpParams p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
@@ -457,7 +457,8 @@ __global__ __launch_bounds__(256, 2) void gptq_gemm_ring_kernel(const ZpParams p
   struct Unit { u32x4 q[4]; u32x4 a[4][MT]; uint32_t z; u32x2 s; };
   auto load_step = [&](int u, int ks, Unit& U) {
     u = min(u, units - 1);  // past the slice: the last unit again (never used)
-    U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_voff, (u * 16 + 4 * ks) * N * 4, 0);
+    // aux 2 = non-temporal when this launch has one row block (M <= 16 MT): the weights are then read exactly once
+    U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_voff, (u * 16 + 4 * ks) * N * 4, NT ? 2 : 0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) U.a[ks][mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], (u * 128 + 32 * ks) * 2, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -813,8 +814,11 @@ extern "C" int nmx_gptq_gemm(const void* a, const int32_t* qweight, const int32_
     // keep >= 2 units (256 k) per wave so that the ring has something to overlap
     while (p.k_splits > 1 && (k / 128) / (p.k_splits * 4) < 2) p.k_splits /= 2;
     grid.y = p.k_splits;
-    if (use_exllama) { if (mt == 1) gptq_gemm_ring_kernel<1, true><<<grid, 256, smem, stream>>>(p); else gptq_gemm_ring_kernel<2, true><<<grid, 256, smem, stream>>>(p); }
-    else { if (mt == 1) gptq_gemm_ring_kernel<1, false><<<grid, 256, smem, stream>>>(p); else gptq_gemm_ring_kernel<2, false><<<grid, 256, smem, stream>>>(p); }
+    const bool nt = m_blocks == 1 && getenv("NMX_GPTQ_NT") != nullptr;  // measured: no gain (2.70 vs 2.65 ms at batch 1): off
+#define NMX_RING(MT_, SH) do { if (nt) gptq_gemm_ring_kernel<MT_, SH, true><<<grid, 256, smem, stream>>>(p); else gptq_gemm_ring_kernel<MT_, SH, false><<<grid, 256, smem, stream>>>(p); } while (0)
+    if (use_exllama) { if (mt == 1) NMX_RING(1, true); else NMX_RING(2, true); }
+    else { if (mt == 1) NMX_RING(1, false); else NMX_RING(2, false); }
+#undef NMX_RING
     NMX_LAUNCH_CHECK();
     if (p.k_splits > 1) {
       const int64_t mn4 = (int64_t)m * n / 4;

@@ -3,7 +3,7 @@ weight tensors captured in a HIP graph (dependent-launch boundaries included, no
 configuration against the default path of the skinny kernel on the same inputs.
 
 usage (GPU box): python3 tools/lean_sweep.py [M ...] > gpurun_out/lean_sweep.txt
-cfg strings: "L:nw,splits[,mt[,ws]]" = marlin_decode_kernel, "G:ngrp" = marlin_large_kernel, "S:mt,ng,splits[,w8]" = marlin_gemm_kernel, "S:auto" its heuristic."""
+cfg strings: "D:auto" = default dispatch, "L:nw,splits[,mt[,ws]]" = marlin_decode_kernel, "G:ngrp" = marlin_large_kernel, "S:mt,ng,splits[,w8]" = marlin_gemm_kernel, "S:auto" its heuristic."""
 import os
 import sys
 
@@ -21,6 +21,8 @@ def set_cfg(cfg):
     for k in ("NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP"):
         os.environ.pop(k, None)
     kind, val = cfg.split(":")
+    if kind == "D":  # default dispatch, no override
+        return
     if kind == "G":  # large-M kernel with 64 * val columns per workgroup
         os.environ["NMX_GEMM_LARGE"] = "1"
         os.environ["NMX_GEMM_LARGE_NGRP"] = val
