@@ -41,6 +41,10 @@ namespace {
 #define NMX_W_NT 1
 #endif
 
+#ifndef NMX_SKINNY_NT
+#define NMX_SKINNY_NT 1  // 16-row tiles of marlin_gemm_kernel (always one row block): non-temporal weight loads, -1.5 % (down at M <= 16)
+#endif
+
 constexpr int kSubSteps = 4;  // 32-k steps per activation staging sub-chunk (128 k)
 
 enum WeightKind { W_INT4 = 0, W_INT8 = 1, W_FP8 = 2 };
@@ -83,6 +87,12 @@ __device__ __forceinline__ void buf_load_x4(u32x4& dst, int voff, i32x4 rsrc, in
   soff = __builtin_amdgcn_readfirstlane(soff);
   asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+// the same with the non-temporal hint (weights that this launch reads exactly once)
+__device__ __forceinline__ void buf_load_x4_nt(u32x4& dst, int voff, i32x4 rsrc, int soff) {
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 __device__ __forceinline__ uint32_t h2_bits(f16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ f16x2 bits_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
 
@@ -628,7 +638,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
         buf_load_x4(r.q1, m_voff, rs_m, kstep * N * 4);
       } else {
         const int soff = 2 * kstep * row_bytes;  // wave-uniform
-        if constexpr (X4) {
+        if constexpr (X4 && MT == 1 && NMX_SKINNY_NT) {
+          buf_load_x4_nt(r.raw, b_voff, rs_b, soff);  // 16-row tiles are only used with one row block
+        } else if constexpr (X4) {
           buf_load_x4(r.raw, b_voff, rs_b, soff);
         } else if constexpr (I4) {
           buf_load_x2(r.q0, b_voff, rs_b, soff);
