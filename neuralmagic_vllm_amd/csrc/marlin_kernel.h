@@ -42,7 +42,7 @@ namespace {
 #endif
 
 #ifndef NMX_SKINNY_NT
-#define NMX_SKINNY_NT 1  // 16-row tiles of marlin_gemm_kernel (always one row block): non-temporal weight loads, -1.5 % (down at M <= 16)
+#define NMX_SKINNY_NT 2  // marlin_gemm_kernel tiles that only run with one row block (16-row tiles; the split-free 128-column 8-wave tile): non-temporal weight loads, -1.5..-4 %
 #endif
 
 constexpr int kSubSteps = 4;  // 32-k steps per activation staging sub-chunk (128 k)
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
         buf_load_x4(r.q1, m_voff, rs_m, kstep * N * 4);
       } else {
         const int soff = 2 * kstep * row_bytes;  // wave-uniform
-        if constexpr (X4 && MT == 1 && NMX_SKINNY_NT) {
+        if constexpr (X4 && NMX_SKINNY_NT && (MT == 1 || (NMX_SKINNY_NT > 1 && MT == 4 && NG == 2 && W8))) {
           buf_load_x4_nt(r.raw, b_voff, rs_b, soff);  // 16-row tiles are only used with one row block
         } else if constexpr (X4) {
           buf_load_x4(r.raw, b_voff, rs_b, soff);
