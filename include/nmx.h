@@ -42,6 +42,11 @@ enum {
 const char* nmx_last_error(void);
 /* library version / build info string, e.g. "nmx 0.1 gfx950" */
 const char* nmx_version(void);
+/* Tuning overrides (kernel sweeps and tests only; results never depend on them). The variables of DESIGN.md §7a
+ * (NMX_GEMM_CFG, NMX_GEMM_WIDE, NMX_ATTN_NW, ...) are read from the environment ONCE, when the library is loaded;
+ * this call changes one afterwards (value NULL = unset). Not thread-safe against concurrent launches. No reference
+ * counterpart (the reference has no such overrides). */
+int nmx_tuning_set(const char* name, const char* value);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Paged attention (decode). Replaces paged_attention_v1 / paged_attention_v2

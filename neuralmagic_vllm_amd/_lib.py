@@ -26,8 +26,15 @@ def lib() -> ctypes.CDLL:
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.nmx_last_error.restype = ctypes.c_char_p
         _lib.nmx_version.restype = ctypes.c_char_p
-        _lib.nmx_marlin_gemm_scratch_bytes.restype = ctypes.c_int64
+        for fn in ("nmx_marlin_gemm_scratch_bytes", "nmx_zp_gemm_scratch_bytes", "nmx_scaled_mm_scratch_bytes"):
+            getattr(_lib, fn).restype = ctypes.c_int64
+        _lib.nmx_tuning_set.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     return _lib
+
+
+def set_tuning(name: str, value=None) -> None:
+    """Kernel sweeps / tests: override (or clear, value=None) one of the NMX_* tuning variables after load."""
+    check(lib().nmx_tuning_set(name.encode(), None if value is None else str(value).encode()))
 
 
 def check(rc: int) -> None:

@@ -61,6 +61,8 @@ extern "C" int64_t nmx_marlin_gemm_scratch_bytes(int size_m, int size_n, int siz
   int splits = c.splits;
   if (size_m > 128) splits = std::max(splits, large_splits(size_m, size_n, size_k));
   splits = std::max(splits, pick_decode_cfg(size_m, size_n, size_k).splits);
+  NmxWideCfg wc;  // group layout unknown here: channel-wise and 128-groups pick the same tile shape
+  if (nmx_wide_pick(size_m, size_n, size_k, 1, size_k, &wc)) splits = std::max(splits, wc.splits);
   return splits > 1 ? (int64_t)splits * size_m * size_n * sizeof(float) : 0;
 }
 

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "nmx_common.h"
+#include "marlin_wide_api.h"
 
 namespace {
 
@@ -1420,7 +1421,7 @@ GemmCfg pick_cfg(int M, int N, int K) {
   // one 64-row block and >= 256 column groups: 128-column tiles (8 waves = 2 column groups x 4 K slices) fill the chip
   // without any cross-workgroup K split - no fp32 partials, no reduce launch (gate_up at M = 64: 29.8 us vs 30.5-33.6)
   if (c.mt == 4 && M <= 64 && n64 >= 448 && K <= 8192) c.ng = 2;
-  if (const char* e = getenv("NMX_GEMM_CFG")) {  // tuning override: "mt,ng,splits[,w8]"
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_CFG)) {  // tuning override: "mt,ng,splits[,w8]"
     int a = 0, b = 0, s = 0, w = 0;
     const int got = sscanf(e, "%d,%d,%d,%d", &a, &b, &s, &w);
     const bool w8 = got == 4 && w != 0 && a == 4;
@@ -1512,7 +1513,7 @@ inline bool use_large(const GemmParams& p, bool sp24) {
   if (sp24 || p.M <= 128 || p.perm != nullptr || p.slow_act_order || p.K % 64 != 0 || p.N % 64 != 0) return false;
   if (p.num_groups > 1 && p.group_size % 64 != 0) return false;
   if ((int64_t)p.M * p.K * 2 >= (1ll << 31) || (int64_t)p.K * p.N >= (1ll << 31)) return false;
-  if (const char* e = getenv("NMX_GEMM_LARGE")) return atoi(e) != 0;
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_LARGE)) return atoi(e) != 0;
   // measured (bench.py --sweep): the 256 x 256 tiles win once they alone fill the chip (>= 192 workgroups without K
   // splits: gate_up from M = 512, qkv at M = 2048); narrower matrices stay on the 64-row row-block path
   return ceil_div(p.N, 256) * ceil_div(p.M, 256) >= 192;
@@ -1528,7 +1529,7 @@ int launch_large(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
   }
   p.partial = reinterpret_cast<float*>(scratch);
   int ngrp = 4;  // measured: 0.75-0.90 PFLOP/s at M = 2048 vs 0.65-0.84 for the two-workgroups-per-CU shape
-  if (const char* e = getenv("NMX_GEMM_LARGE_NGRP")) ngrp = atoi(e) == 2 ? 2 : 4;
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_LARGE_NGRP)) ngrp = atoi(e) == 2 ? 2 : 4;
   const size_t smem = (ngrp == 4 ? 2 : 1) * (size_t)(2 * ngrp * 4 * 64 * 16 + 2 * 4 * 256 * 16);
   dim3 grid(ceil_div(p.N, 64 * ngrp), p.k_splits, ceil_div(p.M, 256));
 #define NMX_LAUNCH_LARGE(MODE_, NGRP_)                                                                              \
@@ -1580,7 +1581,7 @@ inline DecodeCfg pick_decode_cfg(int M, int N, int K) {
     // 17.9 vs 18.6 at M = 8 (at M = 16 the per-wave activation loads make it lose: 21.0 vs 20.7)
     c.nw = 4;
   }
-  if (const char* e = getenv("NMX_GEMM_LEAN")) {
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_LEAN)) {
     int nw = 0, sp = 1, mt = 0, ws = 1;
     const int got = sscanf(e, "%d,%d,%d,%d", &nw, &sp, &mt, &ws);
     if (got >= 1 && (nw == 0 || nw == 4 || nw == 8 || nw == 16)) {
@@ -1662,6 +1663,15 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
     }
   }
   if constexpr (!SP) {
+    // M > 64, plain layout: 128-row wave tiles (marlin_wide.hip)
+    NmxWideCfg wc;
+    if (p.perm == nullptr && !p.slow_act_order && nmx_wide_pick(p.M, p.N, p.K, p.num_groups, p.group_size, &wc)) {
+      NmxWideCall call;
+      call.a = p.a; call.b = p.b; call.scales = p.scales; call.c = p.c; call.scratch = scratch; call.scratch_bytes = scratch_bytes;
+      call.M = p.M; call.N = p.N; call.K = p.K; call.num_groups = p.num_groups; call.group_size = p.group_size;
+      call.kind = KIND; call.is_bf16 = __is_same(scalar_t, bf16) ? 1 : 0;
+      return nmx_wide_launch(call, wc, stream);
+    }
     if (use_large(p, false)) return launch_large<scalar_t, KIND>(p, scratch, scratch_bytes, stream);
   }
   GemmCfg cfg = pick_cfg(p.M, p.N, p.K);

@@ -1,0 +1,591 @@
+// marlin_wide_kernel: the Marlin-format W4A16 / W8A16 / fp8-W8A16 GEMM for M > 64 (the MFMA-bound regime of large decode
+// batches and prefill). Same op contract as marlin_kernel.h (reference: csrc/quantization/gptq_marlin/gptq_marlin.cu:1735-1868,
+// large-M tile table :1395-1412), different work decomposition:
+//
+//   * every wave owns a 128-row x 64-column output tile (8 x 4 MFMA 16x16x32 accumulators = 128 registers) and streams
+//     the packed weights of its 64 columns HBM -> VGPR -> dequant -> MFMA A operand exactly like marlin_gemm_kernel
+//     (no LDS round trip for weights), but each dequantised fragment now feeds 8 MFMAs instead of 4: ~60 dequant VALU
+//     per 32 MFMAs, which fits in the issue slots the MFMAs leave free (2 per 16x16x32);
+//   * a workgroup is 8 waves = WM row halves x WN column groups x WK K-slices. The K-slices of a workgroup dequantise
+//     DIFFERENT weights (no redundant conversion) and are summed through LDS at the end, so a 256 x 128 tile fills the
+//     chip on wide matrices (gate_up: 224 workgroups) with no fp32 partials in HBM and no reduce launch;
+//   * activations are staged per K-slice into LDS in MFMA fragment order, 64 k per stage, double-buffered, from ONE
+//     register set that is refilled right after it has been written (loads of stage s + 2 fly during stage s + 1);
+//   * MFMAs and the int4 -> fp16 conversion are ordered asm statements ([MFMA, 2 VALU] pairs); loads are compiler-visible
+//     buffer intrinsics issued in one fixed periodic order, so hipcc's own counted vmcnt waits keep them in flight.
+//
+// Algorithmic bytes per call: K*N*bits/8 + groups*N*2 + 2*M*K + 2*M*N; flops 2*M*N*K.
+#include "marlin_kernel.h"
+#include "marlin_wide_api.h"
+
+namespace {
+
+// Timing ablations (tools/wide_ablate.sh; results are WRONG when set, never defined in the product build): bit 0 skip
+// MFMAs, 1 skip dequant, 2 skip LDS fragment reads, 3 skip barriers, 4 skip LDS writes, 5 skip activation loads,
+// 6 skip weight loads
+#ifndef NMX_WABLATE
+#define NMX_WABLATE 0
+#endif
+#ifndef NMX_WIDE_ROT
+#define NMX_WIDE_ROT 1   // rotate every workgroup's K order (see stage_of)
+#endif
+#ifndef NMX_WIDE_NT
+#define NMX_WIDE_NT 0    // non-temporal weight loads
+#endif
+
+// ---- single instructions as ordered asm statements ------------------------------------------------------------------
+// hipcc's scheduler bunches the dequantisation in front of the MFMAs and makes every group of four MFMAs wait for a
+// just-issued ds_read (measured: 0.36 of the MFMA rate). asm volatile statements keep their program order, so the
+// instruction stream below is the one written: [MFMA, 2 VALU] pairs - tools/probes/valu_mfma_probe.hip measures two
+// plain or packed-f16 VALU per v_mfma_f32_16x16x32 as nearly free (+8 %) and every further one at ~4 cycles.
+__device__ __forceinline__ void a_mfma_f16(f32x4& acc, const u32x4& a, const u32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void a_mfma_bf16(f32x4& acc, const u32x4& a, const u32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void a_and_or(uint32_t& d, uint32_t q, uint32_t mask_s, uint32_t magic_v) {
+  asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(q), "s"(mask_s), "v"(magic_v));
+}
+__device__ __forceinline__ void a_pk_add(uint32_t& d, uint32_t c_s) { asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(d) : "s"(c_s)); }
+__device__ __forceinline__ void a_pk_fma(uint32_t& d, uint32_t b_s, uint32_t c_v) {
+  asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(d) : "s"(b_s), "v"(c_v));
+}
+// d *= (s.half[H], s.half[H]): the scale row stays packed as loaded, op_sel broadcasts one half to both lanes
+template <int H>
+__device__ __forceinline__ void a_pk_mul_h(uint32_t& d, uint32_t s_v) {
+  if constexpr (H == 0) asm volatile("v_pk_mul_f16 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d) : "v"(s_v));
+  else asm volatile("v_pk_mul_f16 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]" : "+v"(d) : "v"(s_v));
+}
+__device__ __forceinline__ void a_lshr8(uint32_t& d, uint32_t q) { asm volatile("v_lshrrev_b32 %0, 8, %1" : "=v"(d) : "v"(q)); }
+
+struct WFrag { uint32_t w[4][4]; };  // four MFMA operand fragments (tile t, dword)
+
+// Operation j of the int4 -> fp16 conversion of one k-step (two packed words per tile pair; tile t = column
+// c8 + 8 t + 32 hi uses word t >> 1, the "+8 column" half sits 8 bits up). Per tile 12 operations (13 for odd tiles):
+// [2 shifts] 4 x and_or, 2 x (pk_add, pk_fma) = exact (v - 8), then (SCALED) 4 x pk_mul by the group scale - the same
+// arithmetic as Dequant<f16, W_INT4>. The order keeps dependent operations >= 4 apart.
+template <bool SCALED>
+struct DqPlan {
+  static constexpr int PER_EVEN = SCALED ? 12 : 8, PER_ODD = PER_EVEN + 2, TOTAL = 2 * (PER_EVEN + PER_ODD);
+};
+template <bool SCALED, int J>
+__device__ __forceinline__ void dq_op(const u32x2& q0, const u32x2& q1, const u32x2& sc, WFrag& f, uint32_t (&tmp)[2],
+                                      uint32_t magic, uint32_t neg72) {
+  using P = DqPlan<SCALED>;
+  constexpr int PAIR = P::PER_EVEN + P::PER_ODD;
+  constexpr int tp = J / PAIR, r = J % PAIR;             // tile pair, op inside the pair
+  constexpr bool odd = r >= P::PER_EVEN;
+  constexpr int t = 2 * tp + (odd ? 1 : 0);
+  constexpr int o = odd ? r - P::PER_EVEN - 2 : r;       // op inside the tile (-2, -1 = the shifts)
+  if constexpr (odd && o == -2) a_lshr8(tmp[0], q0[tp]);
+  else if constexpr (odd && o == -1) a_lshr8(tmp[1], q1[tp]);
+  else if constexpr (o < 4) {
+    const uint32_t src = odd ? tmp[o >> 1] : ((o >> 1) ? q1[tp] : q0[tp]);
+    a_and_or(f.w[t][o], src, (o & 1) ? 0x00f000f0u : 0x000f000fu, magic);
+  } else if constexpr (o < 8) {
+    constexpr int e = o - 4;
+    if constexpr ((e & 1) == 0) a_pk_add(f.w[t][e], 0xe408e408u);       // (1024 + v) - 1032
+    else a_pk_fma(f.w[t][e], 0x2c002c00u, neg72);                        // (1024 + 16 v) / 16 - 72
+  } else {
+    a_pk_mul_h<t & 1>(f.w[t][o - 8], sc[t >> 1]);  // scale of tile t = half t & 1 of word t >> 1 of the scale row
+  }
+}
+
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK>
+__global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const GemmParams p) {
+  constexpr bool I4 = (KIND == W_INT4);
+  constexpr bool FAST = I4 && __is_same(scalar_t, f16);  // hand-placed conversion; other kinds: compiler-scheduled
+  constexpr bool SCALED = (MODE == 1);
+  constexpr int MT = 8;                         // 16-row MFMA tiles per wave
+  constexpr int NTILE = 4;                      // 16-column MFMA tiles per wave
+  constexpr int BM = 128 * WM;
+  constexpr int TS = 64 * WM * WN;              // threads of one K-slice
+  constexpr int NA = BM * 8 / TS;               // 16-byte activation pieces per thread and 64-k stage
+  constexpr int A_IMG = BM * 128;               // bytes of one stage image [k-step 2][g 4][row BM][16 B]
+  constexpr int WORDS64 = I4 ? 128 : 256;       // int32 per (k-tile, 64-column group)
+  // load issue order per iteration: [batch(s + 2)] [W(2 s + 5)] [W(2 s + 6)]; hipcc derives the counted vmcnt waits
+  static_assert(NA == 4 || NA == 8, "activation pieces per thread");
+  using bvec_t = typename std::conditional<I4, u32x2, u32x4>::type;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15, c8 = li & 7, hi = li >> 3;
+  const int wn = wave % WN, wm = (wave / WN) % WM, wk = wave / (WN * WM);
+  const int N = p.N, K = p.K, M = p.M;
+
+  // blockIdx.x -> (column tile, row block); the row blocks of one column tile are 8 ids apart = same XCD (placement is
+  // a speed matter only: the second row block then finds the tile's weights in that XCD's L2)
+  const int m_blocks = (M + BM - 1) / BM;
+  const int bx_group = blockIdx.x / (8 * m_blocks), bx_r = blockIdx.x % (8 * m_blocks);
+  const int tile_x = bx_group * 8 + (bx_r & 7);
+  const int block_m = bx_r >> 3;
+  if (tile_x * WN * 64 >= N) return;            // padding workgroup (column tiles are rounded up to a multiple of 8)
+  const int n0 = (tile_x * WN + wn) * 64;
+  const bool col_ok = n0 < N;
+  const int m0 = block_m * BM;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* abuf = smem + (size_t)wk * 2 * A_IMG;
+
+  // ---- K range of this slice, in 64-k stages; every slice of the workgroup runs `per` iterations (shared barriers) ----
+  const int total_stages = K / 64;
+  const int workers = p.k_splits * WK;
+  const int per = (total_stages + workers - 1) / workers;
+  const int worker = blockIdx.y * WK + wk;
+  const int st_begin = min(worker * per, total_stages), st_end = min(st_begin + per, total_stages);
+  const int nst = st_end - st_begin;             // stages this slice really has (the rest of `per` multiply zeros)
+  // Every column tile reads the SAME activation rows; workgroups that walk K in the same order hit the same few L2 lines
+  // at the same time (28-32 requesters per line and XCD). Each workgroup therefore starts its K walk at its own offset
+  // and wraps around: the sum is the same set of products, accumulated in a rotated order.
+  const int n_tiles8 = (N + 64 * WN * 8 - 1) / (64 * WN * 8);
+  const int rot = (NMX_WIDE_ROT && nst > 1) ? (int)(((int64_t)(tile_x >> 3) * nst) / n_tiles8 + (block_m * nst) / (2 * m_blocks)) % nst : 0;
+  auto stage_of = [&](int rel) {                 // absolute stage of this slice's rel-th iteration (clamped past the end)
+    int r = min(rel, max(nst - 1, 0)) + rot;
+    r = r >= nst ? r - nst : r;
+    return min(st_begin + max(r, 0), total_stages - 1);
+  };
+
+  // ---- descriptors and per-lane offsets ----
+  const int ktiles = K / 16;
+  const int row_bytes = N * (I4 ? 8 : 16);       // one k-tile row of the packed tensor
+  // Every vector-memory load is a compiler-visible buffer intrinsic: hipcc counts the waits itself and never reads a
+  // destination early. (Inline-asm loads with "+v" destinations were tried first: under register pressure the allocator
+  // re-homed a tied operand with a copy made BEFORE the load had landed - rare wrong scale rows.) The asm MFMA / VALU
+  // statements around them have side effects, so the loads keep the program positions they are given here.
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.b), 0, ktiles * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, M * K * (int)sizeof(scalar_t), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.scales), 0, p.num_groups * N * (int)sizeof(scalar_t), 0x00020000);
+  // weights: lane (g, hi, c8) reads words 2 hi, 2 hi + 1 (int4; 4 words for 8-bit) of chunk 4 c8 + g of both k-tile rows
+  const int b_voff = (((col_ok ? n0 : 0) / 64) * WORDS64 + (4 * c8 + g) * (I4 ? 4 : 8) + (I4 ? 2 : 4) * hi) * 4;
+  // activations: piece i of this thread = row i * (TS / 8) + (tis >> 3), 16-byte chunk cc8 = tis & 7 of the 128-byte
+  // stage row: a wave instruction reads 8 rows x one whole 128-byte line
+  const int tis = (wave % (WM * WN)) * 64 + lane;
+  const int cc8 = tis & 7, aks = cc8 >> 2, acc_ = cc8 & 3;
+  // rows >= M (and every row of a stage past this slice's range) get a voffset beyond the descriptor's range: the
+  // hardware returns zeros without touching memory. Piece i is row (tis >> 3) + i * (TS / 8): valid iff i * (TS / 8) < a_lim.
+  const int a_base = (int)(((int64_t)(m0 + (tis >> 3)) * K + cc8 * 8) * sizeof(scalar_t));
+  const int a_lim = M - m0 - (tis >> 3);
+  const int a_step = (TS / 8) * K * (int)sizeof(scalar_t);  // wave-uniform: goes into the scalar offset
+  // LDS image: fragment (k-step ks, lane group g, row) = 16 bytes at ((ks * 4 + g) * BM + (row ^ 4 ks)) * 16; dword e2 of
+  // piece (row, ks, cc) is dword cc of fragment (ks, g = e2, row). The row ^ 4 ks swizzle puts the two k-steps that one
+  // ds_write_b32 wave-half covers on disjoint banks; the 16 row-lanes of a fragment read stay 16 distinct slots.
+  char* const w_base = abuf + ((aks * 4) * BM + ((tis >> 3) ^ (4 * aks))) * 16 + 4 * acc_;
+  // scales (MODE 1): the lane's four tile columns c8 + 8 t + 32 hi sit at positions 8 c8 + 4 hi + t (scale_perm)
+  const int s_voff = (int)((((col_ok ? n0 : 0) / 64) * 64 + 8 * c8 + 4 * hi) * sizeof(scalar_t));
+
+  struct BStep { bvec_t q0, q1; };
+  BStep ring[4];                                 // k-step j of this slice lives in ring[j & 3]
+  u32x4 areg[NA];
+  u32x2 sraw = {0, 0};
+  u32x2 scc = {0, 0}, scn = {0, 0};              // packed scale rows (4 halves = the lane's 4 tiles) of the current / next stage
+  WFrag wfa, wfb;                                // dequantised fragments of the even / odd k-step of a stage
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ring[i].q0 = bvec_t{}; ring[i].q1 = bvec_t{}; }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) areg[i] = u32x4{0, 0, 0, 0};
+
+  f32x4 acc[MT][NTILE];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue_w = [&](int kstep_rel, BStep& r) {  // k-step 2 rel + ks of this slice's walk
+    const int soff = 2 * (2 * stage_of(kstep_rel >> 1) + (kstep_rel & 1)) * row_bytes;  // never past the tensor
+    if constexpr ((NMX_WABLATE & 64) != 0) return;
+    if constexpr (I4) {
+      r.q0 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff, NMX_WIDE_NT ? 2 : 0);
+      r.q1 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff + row_bytes, NMX_WIDE_NT ? 2 : 0);
+    } else {
+      r.q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff, NMX_WIDE_NT ? 2 : 0);
+      r.q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff + row_bytes, NMX_WIDE_NT ? 2 : 0);
+    }
+  };
+  auto scale_soff = [&](int rel) {
+    const int grp = min((stage_of(rel) * 64) / p.group_size, p.num_groups - 1);
+    return grp * N * (int)sizeof(scalar_t);
+  };
+  // batch(rel): the activation pieces of the rel-th stage of the walk and the scale row of stage rel + 1
+  auto issue_batch = [&](int st) {
+    const int soff = stage_of(st) * 64 * (int)sizeof(scalar_t);
+    const int lim = st < nst ? a_lim : 0;
+    if constexpr ((NMX_WABLATE & 32) == 0) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, i * (TS / 8) < lim ? a_base : (int)0x7ff00000, soff + i * a_step, 0);
+    }
+    if constexpr (SCALED) sraw = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(st + 1), 0);
+  };
+  auto scale_operand = [&](u32x2 v, int t) -> uint32_t {  // what Dequant<>::run expects: (s, s) fp16 pair / fp32 bits
+    union { u32x2 v; scalar_t e[4]; } raw;
+    raw.v = v;
+    if constexpr (__is_same(scalar_t, f16)) {
+      union { f16 h[2]; uint32_t u; } pk;
+      pk.h[0] = raw.e[t];
+      pk.h[1] = raw.e[t];
+      return pk.u;
+    } else {
+      return __builtin_bit_cast(uint32_t, (float)raw.e[t]);
+    }
+  };
+  // LDS writes of activation piece i into buffer `buf` (fragment order)
+  auto write_piece = [&](int i, int buf) {
+    if constexpr ((NMX_WABLATE & 16) != 0) return;
+    char* wb = w_base + buf * A_IMG + i * (TS / 8) * 16;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) *reinterpret_cast<uint32_t*>(wb + e2 * BM * 16) = areg[i][e2];
+  };
+  auto stage_barrier = [&]() {
+    if constexpr ((NMX_WABLATE & 8) != 0) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+  };
+
+  // whole k-step conversion, compiler-scheduled (prologue; and every k-step of the kinds without a hand-placed plan)
+  auto dequant_cxx = [&](const BStep& r, const u32x2& sc, WFrag& f) {
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const uint32_t s2t = SCALED ? scale_operand(sc, t) : 0u;
+      uint32_t w0, w1;
+      if constexpr (I4) {
+        w0 = r.q0[t >> 1] >> (8 * (t & 1));
+        w1 = r.q1[t >> 1] >> (8 * (t & 1));
+      } else {
+        w0 = r.q0[t];
+        w1 = r.q1[t];
+      }
+      if constexpr ((NMX_WABLATE & 2) != 0) {
+        f.w[t][0] = w0; f.w[t][1] = w1; f.w[t][2] = w0 ^ s2t; f.w[t][3] = w1;
+        continue;
+      }
+      Dequant<scalar_t, KIND>::run(w0, s2t, SCALED, f.w[t][0], f.w[t][1]);
+      Dequant<scalar_t, KIND>::run(w1, s2t, SCALED, f.w[t][2], f.w[t][3]);
+    }
+  };
+
+  const uint32_t magic = 0x64006400u, neg72 = 0xd480d480u;
+  const char* const r_base0 = abuf + (g * BM + wm * 128 + li) * 16;
+  const char* const r_base1 = abuf + ((4 + g) * BM + wm * 128 + (li ^ 4)) * 16;
+
+  // One k-step of a stage: 32 MFMAs on fragments `cur` x the 8 activation fragments of (buf, KS); in their shadows the
+  // conversion of the NEXT k-step's packed words `nxt` into `out`, the fragment reads 4 row tiles ahead (KS = 0: running
+  // on into k-step 1's fragments), and (LAND) the wait for + LDS writes of the next stage's activation batch.
+  auto kstep_block = [&](auto ks_c, auto land_c, const WFrag& cur, const BStep& nxt, const u32x2& s2, WFrag& out,
+                         u32x4 (&af)[MT + 4], int buf) {
+    constexpr int KS = decltype(ks_c)::value;
+    constexpr bool LAND = decltype(land_c)::value;
+    const char* rb = (KS == 0 ? r_base0 : r_base1) + buf * A_IMG;
+    const char* rb1 = r_base1 + buf * A_IMG;
+    uint32_t tmp[2];
+    if constexpr (!FAST) dequant_cxx(nxt, s2, out);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      u32x4 wq[NTILE];
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) wq[t] = u32x4{cur.w[t][0], cur.w[t][1], cur.w[t][2], cur.w[t][3]};
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        constexpr int dummy = 0;
+        const int i = mt * NTILE + t;
+        // builtin MFMA here: the compiler pads the VALU-write -> MFMA-read distance of its own conversion code
+        if constexpr ((NMX_WABLATE & 1) != 0) acc[mt][t][0] += __builtin_bit_cast(float, wq[t][mt & 3] ^ af[mt][t & 3]);
+        else acc[mt][t] = mfma_16x16x32<scalar_t>(wq[t], af[mt], acc[mt][t]);
+        (void)dummy; (void)i;
+      }
+      // fragment read 4 row tiles ahead: af[mt + 4] of this k-step, or (KS = 0) af[mt - 4] of k-step 1
+      if constexpr ((NMX_WABLATE & 4) == 0) {
+        if (mt + 4 < MT) af[mt + 4] = *reinterpret_cast<const u32x4*>(rb + (mt + 4) * 256);
+        else if constexpr (KS == 0) af[MT + (mt + 4 - MT)] = *reinterpret_cast<const u32x4*>(rb1 + (mt + 4 - MT) * 256);
+      }
+      if constexpr (LAND) {
+        if constexpr (NA == 8) write_piece(mt, buf ^ 1);
+        else if ((mt & 1) == 0) write_piece(mt >> 1, buf ^ 1);
+      }
+    }
+  };
+  // FAST path: the same block with the conversion operations placed two per MFMA
+  auto kstep_block_fast = [&](auto ks_c, auto land_c, const WFrag& cur, const BStep& nxt, const u32x2& s2, WFrag& out,
+                              u32x4 (&af)[MT + 4], int buf) {
+    constexpr int KS = decltype(ks_c)::value;
+    constexpr bool LAND = decltype(land_c)::value;
+    const char* rb = (KS == 0 ? r_base0 : r_base1) + buf * A_IMG;
+    const char* rb1 = r_base1 + buf * A_IMG;
+    uint32_t tmp[2];
+    u32x4 wq[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) wq[t] = u32x4{cur.w[t][0], cur.w[t][1], cur.w[t][2], cur.w[t][3]};
+    constexpr int NOPS = DqPlan<SCALED>::TOTAL;
+    auto ops = [&](auto i_c) {  // the two conversion operations behind MFMA number i
+      constexpr int I = decltype(i_c)::value;
+      if constexpr ((NMX_WABLATE & 2) == 0) {
+        if constexpr (I4) {
+          if constexpr (2 * I < NOPS) dq_op<SCALED, 2 * I>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
+          if constexpr (2 * I + 1 < NOPS) dq_op<SCALED, 2 * I + 1>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
+        }
+      }
+    };
+    auto row = [&](auto mt_c) {
+      constexpr int mt = decltype(mt_c)::value;
+      a_mfma_f16(acc[mt][0], wq[0], af[KS == 0 ? mt : (mt < 4 ? MT + mt : mt)]);
+      ops(std::integral_constant<int, mt * 4 + 0>{});
+      a_mfma_f16(acc[mt][1], wq[1], af[KS == 0 ? mt : (mt < 4 ? MT + mt : mt)]);
+      ops(std::integral_constant<int, mt * 4 + 1>{});
+      a_mfma_f16(acc[mt][2], wq[2], af[KS == 0 ? mt : (mt < 4 ? MT + mt : mt)]);
+      ops(std::integral_constant<int, mt * 4 + 2>{});
+      a_mfma_f16(acc[mt][3], wq[3], af[KS == 0 ? mt : (mt < 4 ? MT + mt : mt)]);
+      ops(std::integral_constant<int, mt * 4 + 3>{});
+      if constexpr ((NMX_WABLATE & 4) == 0) {
+        if constexpr (mt + 4 < MT) af[mt + 4] = *reinterpret_cast<const u32x4*>(rb + (mt + 4) * 256);
+        else if constexpr (KS == 0) af[MT + (mt + 4 - MT)] = *reinterpret_cast<const u32x4*>(rb1 + (mt + 4 - MT) * 256);
+      }
+      if constexpr (LAND) {
+        if constexpr (NA == 8) write_piece(mt, buf ^ 1);
+        else if constexpr ((mt & 1) == 0) write_piece(mt >> 1, buf ^ 1);
+      }
+    };
+    row(std::integral_constant<int, 0>{});
+    row(std::integral_constant<int, 1>{});
+    row(std::integral_constant<int, 2>{});
+    row(std::integral_constant<int, 3>{});
+    row(std::integral_constant<int, 4>{});
+    row(std::integral_constant<int, 5>{});
+    row(std::integral_constant<int, 6>{});
+    row(std::integral_constant<int, 7>{});
+  };
+
+  // ---- prologue, in the steady-state issue order ----
+  if constexpr (SCALED) scc = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(0), 0);
+  issue_w(0, ring[0]);
+  issue_batch(0);
+  issue_w(1, ring[1]);
+  issue_w(2, ring[2]);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) write_piece(i, 0);
+  scn = sraw;
+  dequant_cxx(ring[0], scc, wfa);
+  issue_batch(1);
+  issue_w(3, ring[3]);
+  issue_w(4, ring[0]);
+  stage_barrier();
+
+  using KS0 = std::integral_constant<int, 0>;
+  using KS1 = std::integral_constant<int, 1>;
+  using NOLAND = std::integral_constant<bool, false>;
+  using DOLAND = std::integral_constant<bool, true>;
+  auto body = [&](auto par_c, int it) {
+    constexpr int PAR = decltype(par_c)::value;   // = it & 1: LDS buffer, and ring slots 2 PAR + {1, 2}
+    const int st = it;  // relative stage of the walk
+    BStep& r1 = ring[(2 * PAR + 1) & 3];
+    BStep& r2 = ring[(2 * PAR + 2) & 3];
+    u32x4 af[MT + 4];  // 0..7: k-step 0, 8..11: first four of k-step 1 (then 4..7 again)
+    if constexpr ((NMX_WABLATE & 4) == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(r_base0 + PAR * A_IMG + mt * 256);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT + 4; ++mt) af[mt] = u32x4{(uint32_t)lane, (uint32_t)it, (uint32_t)mt, 0x3c003c00u};
+    }
+    if constexpr (FAST) {
+      kstep_block_fast(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR);
+      kstep_block_fast(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af, PAR);
+    } else {
+      kstep_block(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR);
+      // k-step 1 of the generic path reads its fragments 4..7 into af[4..7] and 0..3 from af[8..11]
+      u32x4 af1[MT + 4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af1[mt] = af[MT + mt];
+      kstep_block(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af1, PAR);
+    }
+    scc = scn;
+    scn = sraw;
+    issue_batch(st + 2);
+    issue_w(2 * st + 5, r1);
+    issue_w(2 * st + 6, r2);
+    stage_barrier();
+  };
+  for (int it = 0; it < per; it += 2) {
+    body(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < per) body(std::integral_constant<int, 1>{}, it + 1);
+  }
+  // the s_nop covers the MFMA -> VALU read distance that hipcc does not know about (the MFMAs are asm statements)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    asm volatile("s_nop 7" : "+v"(acc[mt][0]), "+v"(acc[mt][1]), "+v"(acc[mt][2]), "+v"(acc[mt][3]));
+
+  // ---- channel-wise scales on the fp32 accumulators (D row 4 g + r of tile t = column 32 (g >> 1) + 8 t + 4 (g & 1) + r;
+  //      scale_perm_single: position 32 (b >> 2) + 8 (cc >> 1) + (cc & 1) + 2 (b & 3) holds column cc + 8 b) ----
+  if constexpr (MODE == 0) {
+    const scalar_t* sc = reinterpret_cast<const scalar_t*>(p.scales) + (col_ok ? n0 : 0);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 32 * (g >> 1) + 8 * t + 4 * (g & 1) + r;
+        const int cc = col & 7, b = col >> 3;
+        const float sv = Scalar<scalar_t>::to_f32(sc[32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3)]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][t][r] *= sv;
+      }
+  }
+
+  // ---- sum the WK K-slices (tree through LDS); slice 0 stores ----
+  constexpr int ACC_FLOATS = MT * NTILE * 64 * 4;
+  if constexpr (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    const int wslot = wave % (WM * WN);
+#pragma unroll
+    for (int stride = WK / 2; stride >= 1; stride >>= 1) {
+      __syncthreads();
+      if (wk >= stride && wk < 2 * stride) {
+        float* dst = red + ((wk - stride) * (WM * WN) + wslot) * ACC_FLOATS;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) *reinterpret_cast<f32x4*>(dst + ((mt * NTILE + t) * 64 + lane) * 4) = acc[mt][t];
+      }
+      __syncthreads();
+      if (wk < stride) {
+        const float* src = red + (wk * (WM * WN) + wslot) * ACC_FLOATS;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) acc[mt][t] += *reinterpret_cast<const f32x4*>(src + ((mt * NTILE + t) * 64 + lane) * 4);
+      }
+    }
+  }
+  if (wk != 0 || !col_ok) return;
+
+  // lane (g, li): D rows = 4 consecutive output columns 32 (g >> 1) + 8 t + 4 (g & 1) + r, D col = activation row li
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wm * 128 + mt * 16 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const int n = n0 + 32 * (g >> 1) + 8 * t + 4 * (g & 1);
+      if (p.k_splits == 1) {
+        union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = r.u;
+      } else {
+        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * M + m) * N + n) = acc[mt][t];
+      }
+    }
+  }
+}
+
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK>
+int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
+  constexpr int BM = 128 * WM;
+  const size_t stage = (size_t)WK * 2 * BM * 128;
+  const size_t red = (WK > 1) ? (size_t)(WK / 2) * WM * WN * 8 * 4 * 64 * 4 * sizeof(float) : 0;
+  const size_t smem = std::max(stage, red);
+  dim3 grid(ceil_div(ceil_div(p.N, 64 * WN), 8) * 8 * ceil_div(p.M, BM), p.k_splits, 1);
+  auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK>;
+  if (smem > 64 * 1024)
+    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  kern<<<grid, 64 * WM * WN * WK, smem, stream>>>(p);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+template <typename scalar_t, int KIND, int MODE>
+int launch_wide_shape(const GemmParams& p, const NmxWideCfg& c, hipStream_t stream) {
+  if (c.wm == 2 && c.wn == 2) return launch_wide_cfg<scalar_t, KIND, MODE, 2, 2, 2>(p, stream);
+  if (c.wm == 2 && c.wn == 4) return launch_wide_cfg<scalar_t, KIND, MODE, 2, 4, 1>(p, stream);
+  if (c.wm == 1 && c.wn == 2) return launch_wide_cfg<scalar_t, KIND, MODE, 1, 2, 4>(p, stream);
+  return launch_wide_cfg<scalar_t, KIND, MODE, 1, 4, 2>(p, stream);
+}
+
+template <typename scalar_t, int KIND>
+int launch_wide_kind(const GemmParams& p, const NmxWideCfg& c, hipStream_t stream) {
+  if constexpr (KIND == W_FP8) return launch_wide_shape<scalar_t, KIND, 0>(p, c, stream);  // fp8 Marlin: channel-wise scales only
+  else {
+    if (p.num_groups > 1) return launch_wide_shape<scalar_t, KIND, 1>(p, c, stream);
+    return launch_wide_shape<scalar_t, KIND, 0>(p, c, stream);
+  }
+}
+
+// NMX_GEMM_WIDE = "wm,wn,splits" forces a configuration, "0" disables the kernel (sweeps and tests)
+struct WideEnv {
+  bool set = false, off = false;
+  int wm = 0, wn = 0, splits = 0;
+};
+WideEnv wide_env() {
+  WideEnv w;
+  const char* e = nmx_tune(NMX_TUNE_GEMM_WIDE);
+  if (e == nullptr) return w;
+  int a = 0, b = 0, s = 0;
+  const int got = sscanf(e, "%d,%d,%d", &a, &b, &s);
+  if (got == 1 && a == 0) { w.off = true; return w; }
+  if (got == 3 && (a == 1 || a == 2) && (b == 2 || b == 4) && s >= 1 && s <= 32) { w.set = true; w.wm = a; w.wn = b; w.splits = s; }
+  return w;
+}
+
+}  // namespace
+
+bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg) {
+  const WideEnv env = wide_env();
+  if (env.off || M <= 64 || K % 64 != 0 || N % 64 != 0) return false;
+  if (num_groups > 1 && group_size % 64 != 0) return false;
+  if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)K * N >= (1ll << 31) || (int64_t)num_groups * N * 2 >= (1ll << 31)) return false;
+  NmxWideCfg c;
+  const int stages = K / 64;
+  if (env.set) {
+    c.wm = env.wm; c.wn = env.wn; c.splits = env.splits;
+  } else {
+    c.wm = M <= 128 ? 1 : 2;
+    const int mb = ceil_div(M, 128 * c.wm);
+    // Column tiles: 128 columns (two K slices per 256-row tile, four per 128-row tile) unless 256-column tiles alone give
+    // every CU a workgroup; K splits across workgroups (fp32 partials + reduce launch) only while CUs would stay idle and
+    // a slice keeps >= 8 stages.
+    c.wn = (ceil_div(N, 256) * mb >= 224) ? 4 : 2;
+    const int units = ceil_div(N, 64 * c.wn) * mb;
+    const int wk = 8 / (c.wm * c.wn);
+    c.splits = 1;
+    while (units * c.splits * 2 <= 256 && stages / (c.splits * 2 * wk) >= 8) c.splits *= 2;
+  }
+  c.wk = 8 / (c.wm * c.wn);
+  while (c.splits > 1 && stages / (c.splits * c.wk) < 1) c.splits /= 2;
+  *cfg = c;
+  return true;
+}
+
+int nmx_wide_launch(const NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream) {
+  GemmParams p;
+  p.a = call.a; p.b = call.b; p.meta = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
+  p.M = call.M; p.N = call.N; p.K = call.K; p.num_groups = call.num_groups; p.group_size = call.group_size;
+  p.slow_act_order = 0;
+  p.k_splits = cfg.splits;
+  if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to the splits that fit
+    const int64_t per = (int64_t)p.M * p.N * sizeof(float);
+    const int fit = call.scratch == nullptr ? 1 : (int)std::min<int64_t>(p.k_splits, call.scratch_bytes / per);
+    p.k_splits = std::max(1, fit);
+  }
+  p.partial = reinterpret_cast<float*>(call.scratch);
+  int rc;
+#ifdef NMX_WIDE_MIN  // experiment builds: fp16 int4 only (compile time)
+  rc = launch_wide_kind<f16, W_INT4>(p, cfg, stream);
+#else
+#define NMX_WIDE_KIND(T)                                                            \
+  switch (call.kind) {                                                              \
+    case W_INT4: rc = launch_wide_kind<T, W_INT4>(p, cfg, stream); break;            \
+    case W_INT8: rc = launch_wide_kind<T, W_INT8>(p, cfg, stream); break;            \
+    default: rc = launch_wide_kind<T, W_FP8>(p, cfg, stream); break;                 \
+  }
+  if (call.is_bf16) { NMX_WIDE_KIND(bf16) } else { NMX_WIDE_KIND(f16) }
+#undef NMX_WIDE_KIND
+#endif
+  if (rc != NMX_OK) return rc;
+  if (p.k_splits > 1) {
+    const int64_t mn4 = (int64_t)p.M * p.N / 4;
+    if (call.is_bf16)
+      splitk_reduce_kernel<bf16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<bf16*>(p.c), p.partial, mn4, p.k_splits);
+    else
+      splitk_reduce_kernel<f16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<f16*>(p.c), p.partial, mn4, p.k_splits);
+    NMX_LAUNCH_CHECK();
+  }
+  return NMX_OK;
+}

@@ -1,0 +1,25 @@
+#pragma once
+// Internal (not part of the C-ABI) hand-over between marlin_gemm.hip and marlin_wide.hip: the wide-tile kernel is its
+// own translation unit so that the two heavy template families compile in parallel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct NmxWideCall {
+  const void* a;          // [M, K] fp16 / bf16
+  const int32_t* b;       // Marlin-packed weight
+  const void* scales;     // [num_groups, N], Marlin-permuted
+  void* c;                // [M, N]
+  void* scratch;          // fp32 split-K partials (may be null)
+  int64_t scratch_bytes;
+  int M, N, K;
+  int num_groups, group_size;
+  int kind;               // WeightKind
+  int is_bf16;
+};
+
+// tile configuration of marlin_wide_kernel: wm x wn x wk waves, `splits` K splits across workgroups
+struct NmxWideCfg { int wm, wn, wk, splits; };
+
+// true when the wide kernel handles this problem (M large enough, plain layout); fills the configuration
+__attribute__((visibility("hidden"))) bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg);
+__attribute__((visibility("hidden"))) int nmx_wide_launch(const NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream);

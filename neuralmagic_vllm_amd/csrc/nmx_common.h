@@ -32,6 +32,15 @@ void nmx_set_error(const char* fmt, ...);
 
 #define NMX_LAUNCH_CHECK() NMX_HIP(hipGetLastError())
 
+// ---- tuning overrides (sweeps and tests only; never needed for correct results) ------------------------------------
+// The environment is read ONCE, when the library is loaded; nmx_tuning_set() (include/nmx.h) changes a value afterwards.
+enum NmxTune {
+  NMX_TUNE_GEMM_CFG = 0, NMX_TUNE_GEMM_LEAN, NMX_TUNE_GEMM_LARGE, NMX_TUNE_GEMM_LARGE_NGRP, NMX_TUNE_GEMM_WIDE,
+  NMX_TUNE_ATTN_NW, NMX_TUNE_PREFILL_GQ, NMX_TUNE_MM_NO_LDS, NMX_TUNE_MM_NT, NMX_TUNE_AWQ_NO_RING, NMX_TUNE_GPTQ_NO_RING,
+  NMX_TUNE_GPTQ_NT, NMX_TUNE_COUNT
+};
+__attribute__((visibility("hidden"))) const char* nmx_tune(int id);  // value, or nullptr when unset
+
 // ---- vector types ---------------------------------------------------------------------------------------
 typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

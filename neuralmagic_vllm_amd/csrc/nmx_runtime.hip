@@ -1,6 +1,7 @@
 // Error plumbing, version string and device-attribute queries of libnmx_hip.
 // Device utilities replace csrc/cuda_utils_kernels.cu of the reference.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "nmx_common.h"
@@ -15,6 +16,40 @@ void nmx_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* nmx_last_error(void) { return g_err; }
+
+// ---- tuning registry: environment read once at load, nmx_tuning_set() for sweeps / tests ----
+namespace {
+const char* const kTuneNames[NMX_TUNE_COUNT] = {
+    "NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP", "NMX_GEMM_WIDE", "NMX_ATTN_NW",
+    "NMX_PREFILL_GQ", "NMX_MM_NO_LDS", "NMX_MM_NT", "NMX_AWQ_NO_RING", "NMX_GPTQ_NO_RING", "NMX_GPTQ_NT"};
+struct TuneTable {
+  char value[NMX_TUNE_COUNT][64];
+  bool set[NMX_TUNE_COUNT];
+  TuneTable() {
+    for (int i = 0; i < NMX_TUNE_COUNT; ++i) {
+      const char* e = getenv(kTuneNames[i]);
+      set[i] = e != nullptr;
+      value[i][0] = 0;
+      if (e != nullptr) { strncpy(value[i], e, sizeof(value[i]) - 1); value[i][sizeof(value[i]) - 1] = 0; }
+    }
+  }
+};
+TuneTable g_tune;  // constructed when the library is loaded
+}  // namespace
+
+const char* nmx_tune(int id) { return (id >= 0 && id < NMX_TUNE_COUNT && g_tune.set[id]) ? g_tune.value[id] : nullptr; }
+
+extern "C" int nmx_tuning_set(const char* name, const char* value) {
+  NMX_CHECK(name != nullptr, NMX_ERR_INVALID_ARG, "tuning name is null");
+  for (int i = 0; i < NMX_TUNE_COUNT; ++i) {
+    if (strcmp(name, kTuneNames[i]) != 0) continue;
+    g_tune.set[i] = value != nullptr;
+    if (value != nullptr) { strncpy(g_tune.value[i], value, sizeof(g_tune.value[i]) - 1); g_tune.value[i][sizeof(g_tune.value[i]) - 1] = 0; }
+    return NMX_OK;
+  }
+  nmx_set_error("unknown tuning variable %s", name);
+  return NMX_ERR_INVALID_ARG;
+}
 
 extern "C" const char* nmx_version(void) { return "nmx 0.1 (gfx950, wave64, hand-written HIP)"; }
 

@@ -594,7 +594,7 @@ int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream
   if constexpr (D <= 128) {
     const long wgs = (long)p.num_kv_heads * p.q_tiles * num_seqs * num_partitions;
     int nw = wgs <= 128 ? 8 : 4;
-    if (const char* e = getenv("NMX_ATTN_NW")) nw = atoi(e) == 8 ? 8 : 4;  // sweeps / tests
+    if (const char* e = nmx_tune(NMX_TUNE_ATTN_NW)) nw = atoi(e) == 8 ? 8 : 4;  // sweeps / tests
     if (nw == 8) return launch_attn_nw<scalar_t, KV, D, 8>(p, num_seqs, num_partitions, stream);
   }
   return launch_attn_nw<scalar_t, KV, D, 4>(p, num_seqs, num_partitions, stream);

@@ -337,7 +337,7 @@ int launch(const PrefillParams& p, int batch, int max_input_len, hipStream_t str
   // tokens per sequence only one wave of a workgroup is active and the second head's registers just cost occupancy)
   const bool gq2_ok = D <= 128 && (p.num_heads / p.num_kv_heads) % 2 == 0;
   bool gq2 = gq2_ok && max_input_len >= 256;
-  if (const char* e = getenv("NMX_PREFILL_GQ")) gq2 = gq2_ok && atoi(e) == 2;  // tests / sweeps: force either shape
+  if (const char* e = nmx_tune(NMX_TUNE_PREFILL_GQ)) gq2 = gq2_ok && atoi(e) == 2;  // tests / sweeps: force either shape
   dim3 grid(ceil_div(max_input_len, 64), gq2 ? p.num_heads / 2 : p.num_heads, batch);
   if (gq2) {
     if constexpr (D <= 128) {

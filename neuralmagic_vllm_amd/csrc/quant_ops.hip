@@ -468,11 +468,11 @@ int launch_mm(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t str
   p.partial = scratch;
   dim3 grid(ceil_div(p.N, 64), p.k_splits, ceil_div(p.M, 16 * mt));
   const size_t smem = (size_t)3 * mt * 4 * 64 * 16;
-  if (p.K % 128 == 0 && getenv("NMX_MM_NO_LDS") == nullptr) {
+  if (p.K % 128 == 0 && nmx_tune(NMX_TUNE_MM_NO_LDS) == nullptr) {
     const size_t img = (size_t)4 * (64 + 16 * mt) * 128;
     const size_t smem_l = std::max(img, smem);
     // measured on the fp8 decode step (batch 64): 5.62 ms with the hint, 5.56 without - off unless NMX_MM_NT is set
-    const bool nt = grid.z == 1 && getenv("NMX_MM_NT") != nullptr;
+    const bool nt = grid.z == 1 && nmx_tune(NMX_TUNE_MM_NT) != nullptr;
     switch (mt) {
       case 1: scaled_mm_lds_kernel<out_t, FP8, 1, false><<<grid, 256, smem_l, stream>>>(p); break;
       case 2: scaled_mm_lds_kernel<out_t, FP8, 2, false><<<grid, 256, smem_l, stream>>>(p); break;

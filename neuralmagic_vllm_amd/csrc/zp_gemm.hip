@@ -734,7 +734,7 @@ extern "C" int nmx_awq_gemm(const void* in_feats, const int32_t* kernel, const v
     p.k_splits = scratch ? std::max<int>(1, (int)(scratch_bytes / ((int64_t)m * oc * 4))) : 1;
   dim3 grid(n_tiles, p.k_splits, m_blocks);
   const bool ring = group_size % 128 == 0 && k % 128 == 0 && (int64_t)k * oc / 2 < (1ll << 31) && (int64_t)m * k * 2 < (1ll << 31) &&
-                    getenv("NMX_AWQ_NO_RING") == nullptr;
+                    nmx_tune(NMX_TUNE_AWQ_NO_RING) == nullptr;
   if (ring) {
     while (p.k_splits > 1 && (k / 128) / (p.k_splits * 4) < 1) p.k_splits /= 2;  // >= 1 unit per wave (tiny N: CUs first)
     grid.y = p.k_splits;
@@ -810,11 +810,11 @@ extern "C" int nmx_gptq_gemm(const void* a, const int32_t* qweight, const int32_
     return NMX_OK;
   }
   if (!gather && !per_row && G % 128 == 0 && k % 128 == 0 && (int64_t)k * n / 2 < (1ll << 31) && (int64_t)m * k * 2 < (1ll << 31) &&
-      getenv("NMX_GPTQ_NO_RING") == nullptr) {
+      nmx_tune(NMX_TUNE_GPTQ_NO_RING) == nullptr) {
     // keep >= 2 units (256 k) per wave so that the ring has something to overlap
     while (p.k_splits > 1 && (k / 128) / (p.k_splits * 4) < 2) p.k_splits /= 2;
     grid.y = p.k_splits;
-    const bool nt = m_blocks == 1 && getenv("NMX_GPTQ_NT") != nullptr;  // measured: no gain (2.70 vs 2.65 ms at batch 1): off
+    const bool nt = m_blocks == 1 && nmx_tune(NMX_TUNE_GPTQ_NT) != nullptr;  // measured: no gain (2.70 vs 2.65 ms at batch 1): off
 #define NMX_RING(MT_, SH) do { if (nt) gptq_gemm_ring_kernel<MT_, SH, true><<<grid, 256, smem, stream>>>(p); else gptq_gemm_ring_kernel<MT_, SH, false><<<grid, 256, smem, stream>>>(p); } while (0)
     if (use_exllama) { if (mt == 1) NMX_RING(1, true); else NMX_RING(2, true); }
     else { if (mt == 1) NMX_RING(1, false); else NMX_RING(2, false); }

@@ -17,14 +17,12 @@ TOL = 1e-3
 
 
 @pytest.fixture
-def force(monkeypatch):
+def force(tune):
 
-    def set_(lean=None, cfg=None):
-        for k, v in (("NMX_GEMM_LEAN", lean), ("NMX_GEMM_CFG", cfg)):
-            if v is None:
-                monkeypatch.delenv(k, raising=False)
-            else:
-                monkeypatch.setenv(k, v)
+    def set_(lean=None, cfg=None, wide="0"):
+        # the forced marlin_gemm_kernel / decode-kernel shapes are what these tests are about: keep the wide kernel
+        # (M > 64) out of the way unless a test asks for the default dispatch
+        tune(NMX_GEMM_LEAN=lean, NMX_GEMM_CFG=cfg, NMX_GEMM_WIDE=wide)
 
     return set_
 
@@ -93,7 +91,7 @@ def test_gemm_kernel_forced_tiles(ops, force, cfg, m):
 
 def test_llama_shapes_default_dispatch(ops, force):
     """The shapes the heuristics were fitted on, default dispatch (decode kernel for qkv / o at small M)."""
-    force()
+    force(wide=None)
     for (K, N) in ((4096, 6144), (4096, 4096)):
         w_ref, q, s = make(K, N, 128, seed=4)
         for m in (1, 16, 32, 64):
@@ -104,7 +102,7 @@ def test_llama_shapes_default_dispatch(ops, force):
 def test_wide_n_large_m_default_dispatch(ops, force):
     """gate_up-sized N at M = 200 / 256: the 4-wave 256-column workgroups picked when 8-wave ones would leave a ragged
     second round."""
-    force()
+    force(wide=None)
     K, N = 1024, 28672
     w_ref, q, s = make(K, N, 128, seed=5)
     for m in (200, 256):

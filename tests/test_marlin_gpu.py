@@ -150,14 +150,14 @@ def test_fp8_marlin_gemm(ops, n_chunk, mnk_factors, dtype):
 @pytest.mark.parametrize("num_bits", [4, 8])
 @pytest.mark.parametrize("group_size", [-1, 64, 128])
 @pytest.mark.parametrize("shape", [(129, 256, 512), (300, 320, 1024), (512, 1024, 4096), (1000, 64, 192)])
-def test_marlin_gemm_large_m(ops, monkeypatch, dtype, num_bits, group_size, shape):
+def test_marlin_gemm_large_m(ops, tune, dtype, num_bits, group_size, shape):
     """M > 128 runs the 256 x 256-tile prefill kernel (row / column tiles that are not full, K splits, every mode);
     (1000, 64, 192) has K % 64 != 0 and must take the row-block path."""
     size_m, size_n, size_k = shape
     if group_size > 0 and size_k % group_size:
         pytest.skip("K not a multiple of the group")
     seed_all(11)
-    monkeypatch.setenv("NMX_GEMM_LARGE", "1")  # small shapes: force the tile kernel (the heuristic wants >= 192 tiles)
+    tune(NMX_GEMM_LARGE="1", NMX_GEMM_WIDE="0")  # small shapes: force the tile kernel (the heuristic wants >= 192 tiles)
     w = torch.randn(size_k, size_n, dtype=dtype)
     w_ref, mq, ms, _, _, _ = packing.marlin_quantize(w, num_bits, group_size, False)
     a = torch.randn(size_m, size_k, dtype=dtype)
@@ -169,9 +169,9 @@ def test_marlin_gemm_large_m(ops, monkeypatch, dtype, num_bits, group_size, shap
     assert compute_max_diff(out.cpu(), ref) < tol
 
 
-def test_fp8_marlin_gemm_large_m(ops, monkeypatch):
+def test_fp8_marlin_gemm_large_m(ops, tune):
     seed_all(12)
-    monkeypatch.setenv("NMX_GEMM_LARGE", "1")
+    tune(NMX_GEMM_LARGE="1", NMX_GEMM_WIDE="0")
     size_m, size_n, size_k = 384, 512, 1024
     w = torch.randn(size_k, size_n, dtype=torch.float16)
     w8 = w.to(torch.float8_e4m3fn)

@@ -75,16 +75,16 @@ def test_contexted_kv_attention(ops, heads, head_size, sliding_window, dtype):
 @pytest.mark.parametrize("gq", ["1", "2"])
 @pytest.mark.parametrize("heads", [(8, 2), (8, 1), (6, 3)])
 @pytest.mark.parametrize("head_size", [128, 80])
-def test_two_heads_per_wave_shape(ops, monkeypatch, gq, heads, head_size):
+def test_two_heads_per_wave_shape(ops, tune, gq, heads, head_size):
     """Both launch shapes of the kernel (one / two query heads of a kv head per wave; the second is the default only from
     256 new tokens) on the same ragged case, with alibi, plus a long prompt that takes the default route."""
     seed_all(3)
-    monkeypatch.setenv("NMX_PREFILL_GQ", gq)
+    tune(NMX_PREFILL_GQ=gq)
     c = make_case(5, heads[0], heads[1], head_size, 16, torch.float16, max_q=200, max_ctx=150)
     alibi = torch.rand(heads[0]) * 0.2
     out = run_hip(c, alibi=alibi)
     torch.testing.assert_close(out.float(), run_oracle(c, alibi=alibi).float(), atol=2e-3, rtol=2e-3)
-    monkeypatch.delenv("NMX_PREFILL_GQ")
+    tune(NMX_PREFILL_GQ=None)
     c = make_case(2, heads[0], heads[1], head_size, 16, torch.float16, max_q=400, max_ctx=60, min_len=300)
     torch.testing.assert_close(run_hip(c).float(), run_oracle(c).float(), atol=2e-3, rtol=2e-3)
 

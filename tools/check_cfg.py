@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from neuralmagic_vllm_amd import _custom_ops as ops  # noqa: E402
+from neuralmagic_vllm_amd import _lib  # noqa: E402
 
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
 CFGS = sys.argv[1].split(";") if len(sys.argv) > 1 else ["4,4,2,1", "4,4,1,1", "4,4,4,1", "4,4,2", "4,4,4"]
@@ -20,10 +21,10 @@ for name, (K, N) in SHAPES.items():
     wsp = torch.zeros(N // 64 * 16, dtype=torch.int32, device=dev)
     for M in (64, 100):
         x = torch.randn(M, K, dtype=torch.float16, device=dev)
-        os.environ.pop("NMX_GEMM_CFG", None)
+        _lib.set_tuning("NMX_GEMM_CFG", None)
         ref = ops.gptq_marlin_gemm(x, w, s, e, e, wsp, 4, M, N, K, True).float()
         for cfg in CFGS:
-            os.environ["NMX_GEMM_CFG"] = cfg
+            _lib.set_tuning("NMX_GEMM_CFG", cfg)
             out = ops.gptq_marlin_gemm(x, w, s, e, e, wsp, 4, M, N, K, True).float()
             err = float((out - ref).abs().mean() / ref.abs().mean())
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -38,6 +38,7 @@ def configs():
 def run(labels_path):
     import torch
     from neuralmagic_vllm_amd import _custom_ops as ops
+    from neuralmagic_vllm_amd import _lib
     dev = "cuda:0"
     g = torch.Generator(device=dev)
     g.manual_seed(0)
@@ -51,7 +52,7 @@ def run(labels_path):
     for (name, M, mt, ng, sp) in configs():
         K, N = SHAPES[name]
         x = torch.randn(M, K, dtype=torch.float16, device=dev)
-        os.environ["NMX_GEMM_CFG"] = f"{mt},{ng},{sp}"
+        _lib.set_tuning("NMX_GEMM_CFG", f"{mt},{ng},{sp}")
         for r in range(REPS):
             w = weights[name][r % 3]
             ops.gptq_marlin_gemm(x, w[0], w[1], e, e, ws, 4, M, N, K, True)

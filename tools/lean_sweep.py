@@ -18,20 +18,25 @@ dev = "cuda:0"
 
 
 def set_cfg(cfg):
-    for k in ("NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP"):
-        os.environ.pop(k, None)
+    from neuralmagic_vllm_amd import _lib
+    for k in ("NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP", "NMX_GEMM_WIDE"):
+        _lib.set_tuning(k, None)
     kind, val = cfg.split(":")
     if kind == "D":  # default dispatch, no override
         return
+    if kind == "W":  # wide kernel "wm,wn,splits"
+        _lib.set_tuning("NMX_GEMM_WIDE", val)
+        return
+    _lib.set_tuning("NMX_GEMM_WIDE", "0")
     if kind == "G":  # large-M kernel with 64 * val columns per workgroup
-        os.environ["NMX_GEMM_LARGE"] = "1"
-        os.environ["NMX_GEMM_LARGE_NGRP"] = val
+        _lib.set_tuning("NMX_GEMM_LARGE", "1")
+        _lib.set_tuning("NMX_GEMM_LARGE_NGRP", val)
     elif kind == "L":
-        os.environ["NMX_GEMM_LEAN"] = val
+        _lib.set_tuning("NMX_GEMM_LEAN", val)
     else:
-        os.environ["NMX_GEMM_LEAN"] = "0"
+        _lib.set_tuning("NMX_GEMM_LEAN", "0")
         if val != "auto":
-            os.environ["NMX_GEMM_CFG"] = val
+            _lib.set_tuning("NMX_GEMM_CFG", val)
 
 
 def time_graph(fn, reps=5):
@@ -59,7 +64,16 @@ def time_graph(fn, reps=5):
 def cfgs_for(name, M):
     out = ["S:auto"]
     if M > 64:
-        return out + ["G:2", "G:4", "S:4,4,1,1", "S:4,4,2,1", "S:4,2,1,1"]
+        wm = 1 if M <= 128 else 2
+        out = ["D:", "S:auto"]
+        for wn in (2, 4):
+            for sp in (1, 2, 4, 8):
+                tiles = -(-SHAPES[name][1] // (64 * wn)) * -(-M // (128 * wm))
+                if tiles * sp <= 512 and SHAPES[name][0] // 64 // (sp * 8 // (wm * wn)) >= 4:
+                    out.append(f"W:{wm},{wn},{sp}")
+        if M > 128:
+            out += ["W:1,2,1", "W:1,2,2", "W:1,4,1"]
+        return out + ["G:4"]
     if M <= 16:
         out += ["L:16,1", "L:8,1", "L:8,2", "L:4,2", "L:4,3", "L:4,4", "L:8,1,1,0", "L:4,4,1,0"]
         if name == "down":
@@ -103,7 +117,7 @@ def main():
                             ops.gptq_marlin_gemm(x, w[0], w[1], e, e, wsp, 4, M, N, K, True)
 
                     us = time_graph(run) / NL
-                    print(f"{name:8} M={M:3d} {cfg:12} {us:7.2f} us  {by / us / 1e3:7.0f} GB/s  relerr_vs_default={err:.2e}", flush=True)
+                    print(f"{name:8} M={M:4d} {cfg:12} {us:7.2f} us  {by / us / 1e3:7.0f} GB/s  {2.0 * M * K * N / us / 1e6:7.1f} TFLOP/s  relerr_vs_default={err:.2e}", flush=True)
                 except Exception as ex:  # noqa: BLE001
                     print(f"{name:8} M={M:3d} {cfg:12} FAILED {ex}", flush=True)
                     torch.cuda.synchronize()
