@@ -208,15 +208,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     return grp * N * (int)sizeof(scalar_t);
   };
   // batch(rel): the activation pieces of the rel-th stage of the walk and the scale row of stage rel + 1
-  auto issue_batch = [&](int st) {
+  auto load_piece = [&](int i, int st) {  // activation piece i of the st-th stage of the walk
+    if constexpr ((NMX_WABLATE & 32) != 0) return;
     const int soff = stage_of(st) * 64 * (int)sizeof(scalar_t);
     const int lim = st < nst ? a_lim : 0;
-    if constexpr ((NMX_WABLATE & 32) == 0) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-        areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, i * (TS / 8) < lim ? a_base : (int)0x7ff00000, soff + i * a_step, 0);
-    }
+    areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, i * (TS / 8) < lim ? a_base : (int)0x7ff00000, soff + i * a_step, 0);
+  };
+  auto load_scale = [&](int st) {
     if constexpr (SCALED) sraw = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(st + 1), 0);
+  };
+  auto issue_batch = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) load_piece(i, st);
+    load_scale(st);
   };
   auto scale_operand = [&](u32x2 v, int t) -> uint32_t {  // what Dequant<>::run expects: (s, s) fp16 pair / fp32 bits
     union { u32x2 v; scalar_t e[4]; } raw;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // conversion of the NEXT k-step's packed words `nxt` into `out`, the fragment reads 4 row tiles ahead (KS = 0: running
   // on into k-step 1's fragments), and (LAND) the wait for + LDS writes of the next stage's activation batch.
   auto kstep_block = [&](auto ks_c, auto land_c, const WFrag& cur, const BStep& nxt, const u32x2& s2, WFrag& out,
-                         u32x4 (&af)[MT + 4], int buf) {
+                         u32x4 (&af)[MT + 4], int buf, int st, BStep& refill) {
     constexpr int KS = decltype(ks_c)::value;
     constexpr bool LAND = decltype(land_c)::value;
     const char* rb = (KS == 0 ? r_base0 : r_base1) + buf * A_IMG;
@@ -298,15 +302,23 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         if (mt + 4 < MT) af[mt + 4] = *reinterpret_cast<const u32x4*>(rb + (mt + 4) * 256);
         else if constexpr (KS == 0) af[MT + (mt + 4 - MT)] = *reinterpret_cast<const u32x4*>(rb1 + (mt + 4 - MT) * 256);
       }
+      // (LAND) this stage's LDS writes of the next stage's activations, each piece's registers refilled for stage
+      // st + 2 one step later; the k-step's packed words (ring slot `refill`, consumed by the previous block) are
+      // re-requested here too: the loads are SPREAD over the MFMA rows instead of issued as one burst per iteration -
+      // a CU retires roughly one vector-memory wave instruction per ~38 cycles, and a burst of 13 per wave from all
+      // eight waves at the same point of the loop left the matrix pipes idle meanwhile
       if constexpr (LAND) {
-        if constexpr (NA == 8) write_piece(mt, buf ^ 1);
-        else if ((mt & 1) == 0) write_piece(mt >> 1, buf ^ 1);
+        constexpr int STEP = 8 / NA;
+        if (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
+        if (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
+        if (mt == 1) issue_w(2 * st + 5, refill);
       }
     }
+    if constexpr (LAND) load_piece(NA - 1, st + 2);
   };
   // FAST path: the same block with the conversion operations placed two per MFMA
   auto kstep_block_fast = [&](auto ks_c, auto land_c, const WFrag& cur, const BStep& nxt, const u32x2& s2, WFrag& out,
-                              u32x4 (&af)[MT + 4], int buf) {
+                              u32x4 (&af)[MT + 4], int buf, int st, BStep& refill) {
     constexpr int KS = decltype(ks_c)::value;
     constexpr bool LAND = decltype(land_c)::value;
     const char* rb = (KS == 0 ? r_base0 : r_base1) + buf * A_IMG;
@@ -339,9 +351,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         if constexpr (mt + 4 < MT) af[mt + 4] = *reinterpret_cast<const u32x4*>(rb + (mt + 4) * 256);
         else if constexpr (KS == 0) af[MT + (mt + 4 - MT)] = *reinterpret_cast<const u32x4*>(rb1 + (mt + 4 - MT) * 256);
       }
-      if constexpr (LAND) {
-        if constexpr (NA == 8) write_piece(mt, buf ^ 1);
-        else if constexpr ((mt & 1) == 0) write_piece(mt >> 1, buf ^ 1);
+      if constexpr (LAND) {  // see kstep_block
+        constexpr int STEP = 8 / NA;
+        if constexpr (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
+        if constexpr (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
+        if constexpr (mt == 1) issue_w(2 * st + 5, refill);
       }
     };
     row(std::integral_constant<int, 0>{});
@@ -352,6 +366,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     row(std::integral_constant<int, 5>{});
     row(std::integral_constant<int, 6>{});
     row(std::integral_constant<int, 7>{});
+    if constexpr (LAND) load_piece(NA - 1, st + 2);
   };
 
   // ---- prologue, in the steady-state issue order ----
@@ -364,8 +379,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   for (int i = 0; i < NA; ++i) write_piece(i, 0);
   scn = sraw;
   dequant_cxx(ring[0], scc, wfa);
-  issue_batch(1);
+  // the same order as an iteration issues them: hipcc merges the pending-load state of this path and of the loop's back
+  // edge at the loop head, and any difference turns the first waits of the body into vmcnt(0)
   issue_w(3, ring[3]);
+  issue_batch(1);
   issue_w(4, ring[0]);
   stage_barrier();
 
@@ -387,26 +404,28 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       for (int mt = 0; mt < MT + 4; ++mt) af[mt] = u32x4{(uint32_t)lane, (uint32_t)it, (uint32_t)mt, 0x3c003c00u};
     }
     if constexpr (FAST) {
-      kstep_block_fast(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR);
-      kstep_block_fast(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af, PAR);
+      kstep_block_fast(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR, st, r1);
+      kstep_block_fast(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af, PAR, st, r1);
     } else {
-      kstep_block(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR);
+      kstep_block(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR, st, r1);
       // k-step 1 of the generic path reads its fragments 4..7 into af[4..7] and 0..3 from af[8..11]
       u32x4 af1[MT + 4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) af1[mt] = af[MT + mt];
-      kstep_block(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af1, PAR);
+      kstep_block(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af1, PAR, st, r1);
     }
     scc = scn;
     scn = sraw;
-    issue_batch(st + 2);
-    issue_w(2 * st + 5, r1);
+    load_scale(st + 2);
     issue_w(2 * st + 6, r2);
     stage_barrier();
   };
+  // Always whole pairs of iterations (an odd `per` runs one more, on zero activations): with a conditional second half
+  // there is a control-flow path from body 0 straight back to body 0, and hipcc's wait counts at the loop head then
+  // assume that order of pending loads too (vmcnt(1) / vmcnt(0) in front of the first k-step's conversion).
   for (int it = 0; it < per; it += 2) {
     body(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < per) body(std::integral_constant<int, 1>{}, it + 1);
+    body(std::integral_constant<int, 1>{}, it + 1);
   }
   // the s_nop covers the MFMA -> VALU read distance that hipcc does not know about (the MFMAs are asm statements)
 #pragma unroll

@@ -64,16 +64,10 @@ def time_graph(fn, reps=5):
 def cfgs_for(name, M):
     out = ["S:auto"]
     if M > 64:
-        wm = 1 if M <= 128 else 2
-        out = ["D:", "S:auto"]
-        for wn in (2, 4):
-            for sp in (1, 2, 4, 8):
-                tiles = -(-SHAPES[name][1] // (64 * wn)) * -(-M // (128 * wm))
-                if tiles * sp <= 512 and SHAPES[name][0] // 64 // (sp * 8 // (wm * wn)) >= 4:
-                    out.append(f"W:{wm},{wn},{sp}")
+        out = ["S:auto", "W:1,2,1", "W:1,2,2", "W:1,2,4", "W:1,4,1", "W:1,4,2", "W:1,4,4"]
         if M > 128:
-            out += ["W:1,2,1", "W:1,2,2", "W:1,4,1"]
-        return out + ["G:4"]
+            out += ["W:2,2,1", "W:2,2,2", "W:2,4,1", "W:2,4,2"]
+        return out
     if M <= 16:
         out += ["L:16,1", "L:8,1", "L:8,2", "L:4,2", "L:4,3", "L:4,4", "L:8,1,1,0", "L:4,4,1,0"]
         if name == "down":
