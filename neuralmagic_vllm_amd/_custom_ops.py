@@ -59,22 +59,37 @@ def is_custom_op_supported(op_name: str) -> bool:
 # ---------------------------------------------------------------------------------------------------------
 # scratch for split-K partial sums (owned here, allocated outside graph capture, reused by every call)
 # ---------------------------------------------------------------------------------------------------------
+# One buffer per (device, stream): kernels on two streams never share partial sums. A buffer that has been handed out is
+# NEVER freed: a captured HIP graph has its address baked in, so when a later eager call needs more bytes the old buffer
+# is retired (kept alive in _retired) and a larger one takes its place for new calls - replaying an old graph still
+# writes into memory that belongs to nobody else.
 _scratch = {}
+_retired = []
+_SCRATCH_FLOOR = 64 << 20
 
 
 def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(device).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
-            if buf is None:
+            # capture streams are private to the capture: fall back to the device's largest buffer of any stream
+            cands = [b for (i, _), b in _scratch.items() if i == index]
+            if not cands:
                 raise RuntimeError("nmx: GEMM scratch must be allocated before graph capture "
-                                   "(run one eager call first)")
-            return buf  # the C side degrades to fewer K-splits that fit
-        nbytes = max(nbytes, 64 << 20)
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                                   "(run one eager call, or reserve_scratch(), first)")
+            return max(cands, key=lambda b: b.numel())  # the C side degrades to the K splits that fit
+        if buf is not None:
+            _retired.append(buf)
+        buf = torch.empty(max(nbytes, _SCRATCH_FLOOR), dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf
+
+
+def reserve_scratch(device, nbytes: int = _SCRATCH_FLOOR) -> None:
+    """Sizes the calling stream's split-K scratch once (e.g. for the largest prefill shape) before graphs are captured."""
+    _get_scratch(torch.device(device), int(nbytes))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -636,7 +651,9 @@ def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
 
 
 def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
-                      out_dtype: Type[torch.dtype], bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      out_dtype: Type[torch.dtype], bias: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out: written in place when given (the `Tensor! out` form of the registered op, scaled_mm_entry.cu:47-100)."""
     assert (b.shape[0] % 16 == 0 and b.shape[1] % 16 == 0)
     assert (out_dtype is torch.bfloat16 or out_dtype is torch.float16)
     _dev(a)
@@ -656,9 +673,11 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, s
         raise RuntimeError("cutlass_scaled_mm: scales must be float32")
     if bias is not None and not (bias.numel() == n and bias.is_contiguous() and bias.dim() == 1 and bias.dtype == out_dtype):
         raise RuntimeError("cutlass_scaled_mm: bias must be a contiguous [N] tensor of the output dtype")
-    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    elif not (out.dim() == 2 and out.shape[0] == m and out.shape[1] == n and out.stride(1) == 1 and out.dtype == out_dtype):
+        raise RuntimeError("cutlass_scaled_mm: out must be a row-major [M, N] tensor of the output dtype")
     lib = _lib.lib()
-    lib.nmx_scaled_mm_scratch_bytes.restype = ctypes.c_int64
     scratch = _get_scratch(a.device, int(lib.nmx_scaled_mm_scratch_bytes(c_int(m), c_int(n), c_int(k))))
     _lib.check(_lib.lib().nmx_scaled_mm(_p(out), _p(a), _p(b), _p(scale_a), c_int(scale_a.numel()), _p(scale_b),
                                         c_int(scale_b.numel()), _p(bias), _p(scratch), c_i64(scratch.numel()),
@@ -672,17 +691,28 @@ def scaled_fp8_quant(
     input: torch.Tensor,
     scale: Optional[torch.Tensor] = None,
     batch_dim_padding: Optional[int] = None,
+    out: Optional[torch.Tensor] = None,
+    dynamic_scale_out: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Same contract as vllm/_custom_ops.py:284-320 (padding rows, if any, are left uninitialised)."""
+    """Same contract as vllm/_custom_ops.py:284-320 (padding rows, if any, are left uninitialised).
+    out / dynamic_scale_out: the `Tensor!` operands of static_/dynamic_scaled_fp8_quant (fp8/common.cu:129-165),
+    written in place by the kernel."""
     _dev(input)
-    if batch_dim_padding:
+    if out is not None:
+        if not (out.is_contiguous() and out.dtype == torch.float8_e4m3fn and out.numel() >= input.numel()):
+            raise RuntimeError("scaled_fp8_quant: out must be a contiguous float8_e4m3fn tensor of at least input's size")
+        output = out
+    elif batch_dim_padding:
         shape = (max(batch_dim_padding, input.shape[0]), *input.shape[1:])
         output = torch.empty(shape, device=input.device, dtype=torch.float8_e4m3fn)
     else:
         output = torch.empty_like(input, dtype=torch.float8_e4m3fn)
     x = input if input.is_contiguous() else input.contiguous()
     if scale is None:
-        scale = torch.empty(1, device=input.device, dtype=torch.float32)  # written by the kernel; no zero fill needed
+        # written by the kernel; no zero fill needed
+        scale = dynamic_scale_out if dynamic_scale_out is not None else torch.empty(1, device=input.device, dtype=torch.float32)
+        if scale.dtype != torch.float32 or scale.numel() != 1:
+            raise RuntimeError("scaled_fp8_quant: scale must be a float32 scalar tensor")
         dynamic = 1
     else:
         dynamic = 0
@@ -694,12 +724,19 @@ def scaled_fp8_quant(
     return output, scale
 
 
-def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Same contract as vllm/_custom_ops.py:324-350."""
+def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                      dynamic_scale_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Same contract as vllm/_custom_ops.py:324-350. out / dynamic_scale_out: the `Tensor!` operands of
+    static_/dynamic_scaled_int8_quant (int8_quant_kernels.cu:75-115), written in place by the kernel."""
     _dev(input)
     if not input.is_contiguous():
         raise RuntimeError("input must be contiguous")  # int8_quant_kernels.cu:78
-    output = torch.empty_like(input, dtype=torch.int8)
+    if out is None:
+        output = torch.empty_like(input, dtype=torch.int8)
+    else:
+        if not (out.is_contiguous() and out.dtype == torch.int8 and out.numel() == input.numel()):
+            raise RuntimeError("out must be a contiguous int8 tensor of input's size")
+        output = out
     hidden = input.shape[-1]
     tokens = input.numel() // hidden
     if scale is not None:
@@ -708,7 +745,12 @@ def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None)
         _lib.check(_lib.lib().nmx_scaled_int8_quant(_p(output), _p(input), _p(scale), c_int(tokens), c_int(hidden),
                                                     c_int(_dt(input)), c_int(0), _stream(input)))
         return output, scale
-    input_scales = torch.empty((tokens, 1), device=input.device, dtype=torch.float32)
+    if dynamic_scale_out is not None:
+        if not (dynamic_scale_out.is_contiguous() and dynamic_scale_out.dtype == torch.float32 and dynamic_scale_out.numel() == tokens):
+            raise RuntimeError("scale must be a contiguous float32 tensor with one element per token")
+        input_scales = dynamic_scale_out
+    else:
+        input_scales = torch.empty((tokens, 1), device=input.device, dtype=torch.float32)
     _lib.check(_lib.lib().nmx_scaled_int8_quant(_p(output), _p(input), _p(input_scales), c_int(tokens), c_int(hidden),
                                                 c_int(_dt(input)), c_int(1), _stream(input)))
     return output, input_scales

@@ -55,14 +55,16 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
 
 }  // namespace
 
+// fp32 split-K partial slabs the dispatch can use for (m, n, k): the splits of the path launch_skinny() takes for a plain
+// layout, and of the row-block kernel that act-order / odd group sizes fall back to (the layout is not known here)
 extern "C" int64_t nmx_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k) {
   if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
-  const GemmCfg c = pick_cfg(size_m, size_n, size_k);
-  int splits = c.splits;
-  if (size_m > 128) splits = std::max(splits, large_splits(size_m, size_n, size_k));
-  splits = std::max(splits, pick_decode_cfg(size_m, size_n, size_k).splits);
-  NmxWideCfg wc;  // group layout unknown here: channel-wise and 128-groups pick the same tile shape
+  int splits = pick_cfg(size_m, size_n, size_k).splits;
+  const DecodeCfg dc = pick_decode_cfg(size_m, size_n, size_k);
+  if (dc.nw != 0) splits = std::max(splits, dc.splits);
+  NmxWideCfg wc;  // channel-wise and 64-multiple groups pick the same tile shape
   if (nmx_wide_pick(size_m, size_n, size_k, 1, size_k, &wc)) splits = std::max(splits, wc.splits);
+  else if (size_m > 128 && ceil_div(size_n, 256) * ceil_div(size_m, 256) >= 192) splits = std::max(splits, large_splits(size_m, size_n, size_k));
   return splits > 1 ? (int64_t)splits * size_m * size_n * sizeof(float) : 0;
 }
 

@@ -555,16 +555,20 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
   if (env.set) {
     c.wm = env.wm; c.wn = env.wn; c.splits = env.splits;
   } else {
-    c.wm = M <= 128 ? 1 : 2;
-    const int mb = ceil_div(M, 128 * c.wm);
-    // Column tiles: 128 columns (two K slices per 256-row tile, four per 128-row tile) unless 256-column tiles alone give
-    // every CU a workgroup; K splits across workgroups (fp32 partials + reduce launch) only while CUs would stay idle and
-    // a slice keeps >= 8 stages.
-    c.wn = (ceil_div(N, 256) * mb >= 224) ? 4 : 2;
-    const int units = ceil_div(N, 64 * c.wn) * mb;
-    const int wk = 8 / (c.wm * c.wn);
+    // Measured (tools/lean_sweep.py, 32-launch graph chains over distinct weights, Llama-3-8B shapes, M = 128 .. 2048;
+    // gpurun_out/wide_sweep.log): 128-row x 256-column tiles with two K slices per workgroup win 13-23 % over the 64-row
+    // row-block kernel once they alone give (nearly) every CU a workgroup - gate_up from M = 256, qkv from 1024, o / down
+    // from 2048 - and, with K splits across workgroups, on long K (down from M = 512: 9 %). Below that the row-block
+    // kernel's four waves per SIMD hide the staging latency better and it stays in charge.
+    c.wm = 1;
+    c.wn = 4;
+    const int units = ceil_div(N, 256) * ceil_div(M, 128);
     c.splits = 1;
-    while (units * c.splits * 2 <= 256 && stages / (c.splits * 2 * wk) >= 8) c.splits *= 2;
+    if (units < 192) {
+      if (K < 8192 || units < 64) return false;
+      while (units * c.splits * 2 <= 256 && stages / (c.splits * 2 * 2) >= 16) c.splits *= 2;
+      if (units * c.splits < 192) return false;
+    }
   }
   c.wk = 8 / (c.wm * c.wn);
   while (c.splits > 1 && stages / (c.splits * c.wk) < 1) c.splits /= 2;

@@ -712,7 +712,15 @@ int pick_splits(int n_tiles, int m_blocks, int steps) {
 
 }  // namespace
 
-extern "C" int64_t nmx_zp_gemm_scratch_bytes(int m, int n) { return (int64_t)16 * m * n * sizeof(float); }
+// fp32 partial slabs that awq_gemm / gptq_gemm can use for (m, n): the same pick_splits() the launchers run, on the
+// coarser of their two tilings (AWQ: 128-column tiles) and an unbounded K - an upper bound of the splits either takes,
+// and 0 as soon as the tiles alone fill the chip (prefill: no scratch at all)
+extern "C" int64_t nmx_zp_gemm_scratch_bytes(int m, int n) {
+  if (m <= 0 || n <= 0) return 0;
+  const int mt = m <= 16 ? 1 : 2;
+  const int splits = pick_splits(ceil_div(n, 128), ceil_div(m, 16 * mt), 1 << 20);
+  return splits > 1 ? (int64_t)splits * m * n * sizeof(float) : 0;
+}
 
 extern "C" int nmx_awq_gemm(const void* in_feats, const int32_t* kernel, const void* scaling_factors,
                             const int32_t* zeros, void* out, void* scratch, int64_t scratch_bytes, int m, int k, int oc,

@@ -66,8 +66,9 @@ def register() -> None:
          "bool use_exllama, int bit) -> Tensor", ops.gptq_gemm)
     _def(c, "gptq_shuffle(Tensor! q_weight, Tensor q_perm, int bit) -> ()", ops.gptq_shuffle)
 
+    # the `Tensor!` operands are written in place by the kernels (no temporary, no copy launch; capturable)
     def _scaled_mm(out, a, b, a_scales, b_scales, bias=None):
-        out.copy_(ops.cutlass_scaled_mm(a, b, a_scales, b_scales, out.dtype, bias))
+        ops.cutlass_scaled_mm(a, b, a_scales, b_scales, out.dtype, bias, out=out)
 
     _def(c, "cutlass_scaled_mm(Tensor! out, Tensor a, Tensor b, Tensor a_scales, Tensor b_scales, Tensor? bias) -> ()",
          _scaled_mm)
@@ -75,24 +76,19 @@ def register() -> None:
     c.impl("cutlass_scaled_mm_supports_fp8", ops.cutlass_scaled_mm_supports_fp8, "CompositeExplicitAutograd")
 
     def _static_fp8(out, input, scale):
-        q, _ = ops.scaled_fp8_quant(input, scale)
-        out[:input.shape[0]].copy_(q)
+        ops.scaled_fp8_quant(input, scale, out=out)
 
     def _dynamic_fp8(out, input, scale):
-        q, s = ops.scaled_fp8_quant(input, None)
-        out[:input.shape[0]].copy_(q)
-        scale.copy_(s)
+        ops.scaled_fp8_quant(input, None, out=out, dynamic_scale_out=scale)
 
     _def(c, "static_scaled_fp8_quant(Tensor! out, Tensor input, Tensor scale) -> ()", _static_fp8)
     _def(c, "dynamic_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale) -> ()", _dynamic_fp8)
 
     def _static_i8(out, input, scale):
-        out.copy_(ops.scaled_int8_quant(input, scale)[0])
+        ops.scaled_int8_quant(input, scale, out=out)
 
     def _dynamic_i8(out, input, scale):
-        q, s = ops.scaled_int8_quant(input, None)
-        out.copy_(q)
-        scale.copy_(s)
+        ops.scaled_int8_quant(input, None, out=out, dynamic_scale_out=scale)
 
     _def(c, "static_scaled_int8_quant(Tensor! out, Tensor input, Tensor scale) -> ()", _static_i8)
     _def(c, "dynamic_scaled_int8_quant(Tensor! out, Tensor input, Tensor! scale) -> ()", _dynamic_i8)
