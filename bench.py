@@ -10,6 +10,12 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (
               are torch ops. The step is captured in a HIP graph (the reference decodes under CUDA graphs too:
               vllm/worker/model_runner.py:910-1111).
   value     = decoded tokens / s over all ranks (each rank = an independent TP=1 replica: weak scaling).
+  --gpus N  : run as N ranks of one node. Under `python -m torch.distributed.run` (RANK / WORLD_SIZE set) this process IS
+              one rank; started directly with --gpus N > 1 it first spawns the N ranks as child processes (before any GPU
+              call of its own) and relays rank 0's JSON line.
+  --tp N    : ONE model sharded over the N ranks (Megatron TP, config 5: Llama-3-70B AWQ TP=8): column-parallel qkv /
+              gate_up, row-parallel o / down, each followed by an RCCL all-reduce of [batch, hidden] fp16 INSIDE the
+              captured step (linear.py:791-793 -> parallel_state.py:273-293); value = tokens/s of the whole job (strong).
   roofline  = the kernel class with the largest share of the step, timed with HIP events on the launch stream.
   cpu_baseline = the CPU oracle (a port: dequant + fp32 matmul, scalar attention) on a bounded sample, rank 0 only.
 Synthetic data: random token ids / activations, random-init int4 weights of the Llama-3-8B shapes.
@@ -31,6 +37,20 @@ MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16
 LLAMA3_8B = dict(hidden=4096, inter=14336, heads=32, kv_heads=8, head=128, layers=32, vocab=128256, group=128)
 # one TP=8 rank of Llama-3-70B (8 q heads + 1 kv head, inter 28672 / 8 per rank, 80 layers)
 LLAMA3_70B_TP8_RANK = dict(hidden=8192, inter=3584, heads=8, kv_heads=1, head=128, layers=80, vocab=128256 // 8, group=128)
+LLAMA3_70B = dict(hidden=8192, inter=28672, heads=64, kv_heads=8, head=128, layers=80, vocab=128256, group=128)
+
+
+def tp_shard(cfg, tp):
+    """Per-rank shapes of Megatron TP: q heads / kv heads / intermediate / vocab divided by tp, kv heads
+    replicated once tp exceeds their number (config.py:396-404)."""
+    assert cfg["heads"] % tp == 0 and cfg["inter"] % (tp * 128) == 0, "tp must divide the heads and 128-column tiles of inter"
+    c = dict(cfg)
+    c["heads"] = cfg["heads"] // tp
+    c["kv_heads"] = max(1, cfg["kv_heads"] // tp)
+    c["inter"] = cfg["inter"] // tp
+    c["vocab"] = cfg["vocab"] // tp
+    c["attn_hidden"] = cfg["hidden"]
+    return c
 
 # BASELINE.json configs[1..4]. "int4" is the headline (the metric is quoted on it); the others are selected with
 # --config and print the same JSON line for their own workload.
@@ -49,6 +69,10 @@ VARIANTS = {
                          metric="decode tokens/sec, Llama-3-8B GPTQ-int4 through gptq_gemm (exllama format) TP=1",
                          workload="Llama-3-8B GPTQ-int4 g128 decode step through gptq_gemm after gptq_shuffle - the one quantized "
                                   "GEMM the reference itself builds for ROCm (CMakeLists.txt:149); same model as configs[1]"),
+    "awq70b": dict(model=LLAMA3_70B, kv="auto",
+                   metric="decode tokens/sec, Llama-3-70B AWQ-int4, tensor-parallel over RCCL (use with --tp N)",
+                   workload="Llama-3-70B AWQ-int4 g128 decode step sharded by --tp (configs[4]: TP=8 over xGMI, 2 RCCL all-reduces "
+                            "per layer inside the captured step)"),
     "awq70b-tp8rank": dict(model=LLAMA3_70B_TP8_RANK, kv="auto",
                            metric="decode tokens/sec of ONE TP=8 rank, Llama-3-70B AWQ-int4 (no all-reduce in the timed step)",
                            workload="Llama-3-70B AWQ-int4 g128, the per-rank shard of TP=8 (configs[4]): compute of one rank, "
@@ -67,6 +91,8 @@ def parse():
     ap.add_argument("--ctx", type=int, default=1024, help="KV context length of every sequence")
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--config", choices=sorted(VARIANTS), default="int4", help="which BASELINE.json config to run")
+    ap.add_argument("--tp", type=int, default=0, help="tensor-parallel degree: all ranks share ONE model (needs --gpus == --tp); "
+                    "0 = independent replicas")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
@@ -100,7 +126,7 @@ def random_weight(variant, K, N, group, device, gen):
         q = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=device, generator=gen)
         z = torch.randint(-2**31, 2**31 - 1, (K // group, N // 8), dtype=torch.int32, device=device, generator=gen)
         return q, z, s, torch.empty(0, dtype=torch.int32, device=device)  # no act-order: empty g_idx (gptq.py:207-213)
-    if variant == "awq70b-tp8rank":
+    if variant in ("awq70b-tp8rank", "awq70b"):
         q = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int32, device=device, generator=gen)
         z = torch.randint(-2**31, 2**31 - 1, (K // group, N // 8), dtype=torch.int32, device=device, generator=gen)
         return q, z, s
@@ -110,8 +136,9 @@ def random_weight(variant, K, N, group, device, gen):
 class Llama3Decode:
     """Synthetic Llama-3-8B decode step driver (the *caller* of the hot path; stands in for vllm's LlamaForCausalLM)."""
 
-    def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16, variant="int4"):
+    def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16, variant="int4", all_reduce=None, all_gather=None):
         self.ops, self.cfg, self.B, self.L, self.dev = ops, cfg, batch, ctx, device
+        self.all_reduce, self.all_gather = all_reduce, all_gather  # tensor-parallel collectives (None: TP = 1)
         self.n_layers = n_layers
         self.variant = variant
         self.kv_dtype = VARIANTS[variant]["kv"]
@@ -224,13 +251,19 @@ class Llama3Decode:
                                   self.kv_scale)
             a = self.attention(q.view(-1, nh, D), li)
             h = self.gemm(a.view(-1, nh * D), lw["o"], "o")
+            if self.all_reduce is not None:
+                self.all_reduce(h)  # RowParallelLinear: partial products of the K shards (linear.py:791-793)
             ops.fused_add_rms_norm(h, resid, lw["ln2"], 1e-5)
             gu = self.gemm(h, lw["gate_up"], "gate_up")
             act = torch.empty(gu.shape[0], cfg["inter"], dtype=gu.dtype, device=gu.device)
             ops.silu_and_mul(act, gu)
             h = self.gemm(act, lw["down"], "down")
+            if self.all_reduce is not None:
+                self.all_reduce(h)
         ops.fused_add_rms_norm(h, resid, self.final_ln, 1e-5)
         logits = torch.matmul(h, self.lm_head.t())
+        if self.all_gather is not None:
+            logits = self.all_gather(logits)  # vocab-parallel lm_head (logits_processor.py: gather of the shards)
         self.next_tokens.copy_(logits.argmax(-1))
         return self.next_tokens
 
@@ -243,7 +276,7 @@ def gemm_bytes(M, K, N, group, variant="int4"):
         return K * N // 4 + K * N // 8 + scales + act       # kept values + 2-bit positions
     if variant == "fp8":
         return K * N + M * K + 2 * M * N                      # fp8 weights, fp8 activations
-    if variant in ("awq70b-tp8rank", "gptq-exllama"):
+    if variant in ("awq70b-tp8rank", "awq70b", "gptq-exllama"):
         return K * N // 2 + scales + (K // group) * N // 2 + act  # + packed zero points
     return K * N // 2 + scales + act
 
@@ -380,8 +413,37 @@ def pmc_traffic(kernels, args):
         return None, None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (this parent never touches a GPU -
+    nothing here may exec or re-exec a process that has initialised one) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < n:
+        print(json.dumps({"error": f"--gpus {n} but only {have} GPU(s) visible", "n_gpus": have}), flush=True)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -389,9 +451,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    tp = args.tp
+    if world > 1 or tp > 0:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if "MASTER_ADDR" not in os.environ:  # --tp 1 on one GPU: a world of one, still through RCCL
+            import socket
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
+            sock.close()
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
+    if tp > 0:
+        assert tp == world, f"--tp {tp} needs exactly {tp} ranks (--gpus {tp}); got WORLD_SIZE={world}"
 
     from neuralmagic_vllm_amd import _custom_ops as ops
     var = VARIANTS[args.config]
@@ -399,7 +470,23 @@ def main():
     if args.layers is None:
         args.layers = cfg["layers"]
     cfg["layers"] = args.layers
-    model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev, variant=args.config)
+    all_reduce = all_gather = None
+    if tp > 0:
+        cfg = tp_shard(cfg, tp)
+        # the collectives run on the current (compute / capture) stream, so they are part of the captured step like the
+        # reference's pynccl path (device_communicators/pynccl.py:99-118). world 1 still calls into RCCL.
+        all_reduce = lambda t: dist.all_reduce(t)
+
+        def all_gather(t):
+            out = torch.empty(tp, t.shape[0], t.shape[1], dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t.contiguous())
+            return out.movedim(0, 1).reshape(t.shape[0], tp * t.shape[1])
+
+        warm = torch.ones(8, device=dev, dtype=torch.float16)
+        dist.all_reduce(warm)  # communicator set-up outside the capture
+        torch.cuda.synchronize()
+    model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev, variant=args.config, all_reduce=all_reduce,
+                         all_gather=all_gather)
 
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()
@@ -435,7 +522,25 @@ def main():
         dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.batch * args.steps / dt
+    replicas = 1 if tp > 0 else world
+    value = replicas * args.batch * args.steps / dt
+    ar_stats = None
+    if tp > 0:
+        # the step's all-reduce on its own: 2 per layer of [batch, hidden] fp16, chained in one graph
+        buf = torch.randn(args.batch, cfg["hidden"], device=dev, dtype=torch.float16)
+        n_ar = 2 * args.layers
+
+        def ar_chain():
+            for _ in range(n_ar):
+                dist.all_reduce(buf)
+
+        ar_ms = time_events(ar_chain, 5) / n_ar
+        nbytes = buf.numel() * 2
+        ar_stats = dict(bytes=nbytes, per_step=n_ar, us=round(ar_ms * 1e3, 2),
+                        algbw_GBps=round(nbytes / ar_ms / 1e6, 1),
+                        # ring all-reduce: every rank sends (and receives) 2 (n - 1) / n of the message over its ring links
+                        busbw_GBps_per_link=round(2.0 * (tp - 1) / tp * nbytes / ar_ms / 1e6, 1),
+                        step_share_ms=round(ar_ms * n_ar, 3))
 
     result = None
     if rank == 0:
@@ -444,10 +549,11 @@ def main():
         # kernel classes: the four int4 GEMM launches of a layer are one kernel (marlin_gemm_kernel [+ its split-K reduce]);
         # per-launch figures are the mean over the four shapes, which is what rocprofv3's per-kernel average reports too.
         gem = [v for k, v in kb.items() if "_gemm_" in k]
-        gemm_kernels = {"int4": ("marlin_gemm_kernel", "marlin_decode_kernel", "splitk_reduce_kernel"),
+        gemm_kernels = {"int4": ("marlin_gemm_kernel", "marlin_wide_kernel", "marlin_decode_kernel", "splitk_reduce_kernel"),
                         "sparse24": ("marlin_gemm_kernel", "splitk_reduce_kernel"),
                         "fp8": ("scaled_mm_kernel", ),
                         "gptq-exllama": ("gptq_gemm_kernel", "splitk_reduce_kernel"),
+                        "awq70b": ("awq_gemm_kernel", "splitk_reduce_kernel"),
                         "awq70b-tp8rank": ("awq_gemm_kernel", "splitk_reduce_kernel")}[args.config]
         att = [v for k, v in kb.items() if k.startswith("paged_attention")][0]
         gem_ms = sum(v["ms"] for v in gem)
@@ -488,20 +594,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if tp > 0 else "weak",
             "vs_baseline": None,
             "dtype": "fp8" if args.config == "fp8" else "f16",
             "data": "synthetic",
             "config": {"workload": var["workload"], "batch_per_gpu": args.batch,
                        "context": args.ctx, "layers": args.layers,
                        "kv_cache": ("fp8-e4m3" if model.kv_dtype == "fp8" else "fp16") + " block 16", "hip_graph": graph is not None,
-                       "parallelism": f"dp{world} (independent TP=1 replicas)"},
+                       "parallelism": (f"tp{tp} (one model over {tp} ranks, RCCL all-reduce in the captured step)" if tp > 0
+                                       else f"dp{world} (independent TP=1 replicas)")},
             "roofline": roof,
             "rooflines": rooflines,
             "kernels": {k: {"us": round(v["ms"] * 1e3, 2), "GBps": round(v["gbs"], 1), "TFLOPs": round(v["tflops"], 2),
                             "step_share_ms": round(per_step[k], 3)} for k, v in kb.items()},
             "hot_path_share_of_step": round(sum(per_step.values()) / ms_per_step, 3),
         }
+        if tp > 0:
+            result["tp"] = tp
+            result["allreduce"] = ar_stats
         if args.sweep and args.config == "int4":
             result["sweep"] = sweep(ops, cfg, dev)
         if not args.no_cpu_baseline and args.config == "int4":  # the CPU port times the headline workload only

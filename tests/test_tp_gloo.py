@@ -36,6 +36,8 @@ def _patch_ops_with_oracle():
 
     ops.gptq_marlin_repack = repack
     ops.gptq_marlin_gemm = lambda a, q, s, g, p, ws, bits, m, n, k, full: oracle.gptq_marlin_gemm(a, q, s, g, p, ws, bits, m, n, k, full)
+    ops.awq_gemm = oracle.awq_gemm
+    ops.awq_dequantize = oracle.awq_dequantize
 
 
 def _worker(rank, world, port, ret):
@@ -101,3 +103,64 @@ def test_tp2_gptq_marlin_mlp_gloo():
     for r in range(world):
         assert ret[r] < 2e-3, ret[r]
     assert abs(ret[0] - ret[1]) < 1e-9  # every rank holds the identical reduced result
+
+
+def _worker_awq(rank, world, port, ret):
+    """The AWQ shard rules of BASELINE config 5 (awq.py:76-176 under linear.py:408-445): column-parallel layers split the
+    PACKED output dimension of qweight / qzeros (N / 8 words) and the scales on N, row-parallel layers split K - qweight
+    rows, and qzeros / scales group rows - followed by the one sum all-reduce."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neuralmagic_vllm_amd.distributed import init_distributed_environment
+    init_distributed_environment(backend="gloo")
+    _patch_ops_with_oracle()
+    from oracle import packing
+    from neuralmagic_vllm_amd.layers.linear import MergedColumnParallelLinear, RowParallelLinear
+    from neuralmagic_vllm_amd.layers.quantization.awq import AWQConfig
+    torch.manual_seed(0)
+    H, I, M, G = 256, 512, 5, 128
+    cfg = AWQConfig(4, G, True)
+    gate_up = MergedColumnParallelLinear(H, [I, I], cfg)   # gate and up shards are loaded separately (llama.py:433-470)
+    down = RowParallelLinear(I, H, cfg)
+    w_gate, w_up, w_down = (torch.randn(H, I, dtype=torch.float16) * 0.1 for _ in range(2)), None, torch.randn(I, H, dtype=torch.float16) * 0.1
+    w_gate, w_up = tuple(w_gate)
+    refs = {}
+    for name, w, layer, shard in (("gate", w_gate, gate_up, 0), ("up", w_up, gate_up, 1), ("down", w_down, down, None)):
+        w_ref, qweight, qzeros, scales = packing.awq_quantize(w, G)
+        refs[name] = w_ref
+        for pname, tsr in (("qweight", qweight), ("qzeros", qzeros), ("scales", scales)):
+            prm = getattr(layer, pname)
+            if shard is None:
+                prm.weight_loader(prm, tsr)
+            else:
+                prm.weight_loader(prm, tsr, shard)
+    assert gate_up.qweight.shape == (H, 2 * I // world // 8) and gate_up.scales.shape == (H // G, 2 * I // world)
+    assert down.qweight.shape == (I // world, H // 8) and down.qzeros.shape == (I // world // G, H // 8)
+    x = torch.randn(M, H, dtype=torch.float16)
+    gu = gate_up(x)
+    g, u = gu.chunk(2, dim=-1)
+    y = down((g.float() * u.float()).half())
+    gr, ur = (x.float() @ refs["gate"].float()).half().float(), (x.float() @ refs["up"].float()).half().float()
+    ref = (gr * ur).half().float() @ refs["down"].float()
+    ret[rank] = float((y.float() - ref).abs().mean() / ref.abs().mean())
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tp2_awq_mlp_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_awq, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for r in range(world):
+        assert ret[r] < 3e-3, ret[r]
+    assert abs(ret[0] - ret[1]) < 1e-9

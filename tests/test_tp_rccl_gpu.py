@@ -34,6 +34,28 @@ def test_tp_world1_rccl_mlp(ops):
         t = torch.arange(12, dtype=torch.float16, device=DEV).reshape(3, 4)
         assert torch.equal(tensor_model_parallel_all_reduce(t.clone()), t)
         assert torch.equal(tensor_model_parallel_all_gather(t, dim=-1), t)
+        # the product bypasses the collective at world size 1 like the reference (parallel_state.py:273-276); call RCCL
+        # itself on device tensors here so that the communicator, the kernel launch and graph capture are exercised
+        from neuralmagic_vllm_amd.distributed import get_tp_group
+        grp = get_tp_group().device_group
+        u = t.clone()
+        dist.all_reduce(u, group=grp)
+        gat = torch.empty(1, 3, 4, dtype=torch.float16, device=DEV)
+        dist.all_gather_into_tensor(gat, t, group=grp)
+        torch.cuda.synchronize()
+        assert torch.equal(u, t) and torch.equal(gat[0], t)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            v = t.clone()
+            dist.all_reduce(v, group=grp)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                dist.all_reduce(v, group=grp)  # captured on the compute stream like the decode step of bench.py --tp
+            v.copy_(t * 2)
+            g.replay()
+            side.synchronize()
+        assert torch.equal(v, t * 2)
         seed_all(0)
         H, I, G = 256, 512, 128
         cfg = GPTQMarlinConfig(4, G, False, True)
@@ -58,3 +80,63 @@ def test_tp_world1_rccl_mlp(ops):
         destroy_model_parallel()
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_tp_mode_one_rank():
+    """bench.py --tp: the sharded step with the RCCL all-reduce inside the captured graph (world of one here; the driver
+    runs the 2 / 4 / 8-rank legs). The JSON line must carry tp and the per-all-reduce figures."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "awq70b", "--tp", "1", "--gpus", "1",
+                          "--layers", "2", "--batch", "8", "--ctx", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["tp"] == 1 and r["n_gpus"] == 1 and r["scaling"] == "strong" and r["config"]["hip_graph"] is True
+    assert r["allreduce"]["per_step"] == 4 and r["allreduce"]["bytes"] == 8 * 8192 * 2 and r["allreduce"]["us"] > 0
+
+
+def _tp2_worker(rank, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from neuralmagic_vllm_amd.distributed import init_distributed_environment, tensor_model_parallel_all_reduce
+    torch.cuda.set_device(rank)
+    init_distributed_environment(backend="nccl")
+    t = torch.full((256, 8192), float(rank + 1), dtype=torch.float16, device=f"cuda:{rank}")
+    tensor_model_parallel_all_reduce(t)
+    torch.cuda.synchronize()
+    ret[rank] = float(t.float().mean())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
+def test_tp2_rccl_all_reduce_two_gpus():
+    """Two ranks, one GPU each: the [M, hidden] fp16 sum all-reduce of RowParallelLinear over RCCL / xGMI."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp2_worker, args=(r, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert ret[0] == 3.0 and ret[1] == 3.0
