@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--config", choices=sorted(VARIANTS), default="int4", help="which BASELINE.json config to run")
     ap.add_argument("--tp", type=int, default=0, help="tensor-parallel degree: all ranks share ONE model (needs --gpus == --tp); "
                     "0 = independent replicas")
+    ap.add_argument("--no-fuse", action="store_true", help="int4: run the plain op sequence (split-K reduce launches, separate "
+                    "rotary / reshape_and_cache) instead of the fused consumers - bit-identical results, more launches")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
@@ -139,6 +141,7 @@ class Llama3Decode:
     def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16, variant="int4", all_reduce=None, all_gather=None):
         self.ops, self.cfg, self.B, self.L, self.dev = ops, cfg, batch, ctx, device
         self.all_reduce, self.all_gather = all_reduce, all_gather  # tensor-parallel collectives (None: TP = 1)
+        self.fuse = False  # int4 only: deferred split-K reduction + rotary / cache fusion (set by main)
         self.n_layers = n_layers
         self.variant = variant
         self.kv_dtype = VARIANTS[variant]["kv"]
@@ -227,10 +230,50 @@ class Llama3Decode:
                                         self.kv_scale)
         return out
 
+    def step_fused(self):
+        """The same layer arithmetic with 9 instead of ~14 dependent launches: the split-K partial sums of every int4 GEMM
+        are folded into the element-wise op that consumes them (nmx_*_splitk), and rotary_embedding + reshape_and_cache
+        are one launch. Bit-identical to step() (tests/test_fused_gpu.py)."""
+        cfg, ops = self.cfg, self.ops
+        nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
+        e, ws = self.empty, self.workspace
+
+        def gemm(x, w, name):
+            K, N = self.shapes[name]
+            return ops.gptq_marlin_gemm_deferred(x, w[0], w[1], e, e, ws, 4, x.shape[0], N, K, True)
+
+        h = self.embed[self.tokens]
+        resid = h
+        x = torch.empty_like(h)
+        ops.rms_norm(x, h, self.layers[0]["ln1"], 1e-5)
+        for li, lw in enumerate(self.layers):
+            kc, vc = self.kv[li]
+            qkv = ops.rope_reshape_and_cache(self.positions, gemm(x, lw["qkv"], "qkv"), nh, nkv, D, self.cos_sin_cache, kc, vc,
+                                             self.slot_mapping, self.kv_dtype, self.kv_scale)
+            a = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li)
+            o = gemm(a.view(-1, nh * D), lw["o"], "o")
+            if self.all_reduce is not None:
+                self.all_reduce(o.materialize())
+            h = ops.fused_add_rms_norm_splitk(o, resid, lw["ln2"], 1e-5)
+            act = torch.empty(h.shape[0], cfg["inter"], dtype=h.dtype, device=h.device)
+            ops.silu_and_mul_splitk(act, gemm(h, lw["gate_up"], "gate_up"))
+            d = gemm(act, lw["down"], "down")
+            if self.all_reduce is not None:
+                self.all_reduce(d.materialize())
+            nxt = self.layers[li + 1]["ln1"] if li + 1 < self.n_layers else self.final_ln
+            x = ops.fused_add_rms_norm_splitk(d, resid, nxt, 1e-5)
+        logits = torch.matmul(x, self.lm_head.t())
+        if self.all_gather is not None:
+            logits = self.all_gather(logits)
+        self.next_tokens.copy_(logits.argmax(-1))
+        return self.next_tokens
+
     def step(self):
         """Same op sequence as the reference's LlamaDecoderLayer (vllm/model_executor/models/llama.py:154-230):
         fused_add_rms_norm -> qkv -> rotary_embedding (in place) -> reshape_and_cache -> paged_attention -> o_proj ->
         fused_add_rms_norm -> gate_up -> silu_and_mul -> down."""
+        if self.fuse:
+            return self.step_fused()
         cfg, ops = self.cfg, self.ops
         nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
         h = self.embed[self.tokens]
@@ -488,6 +531,7 @@ def main():
     model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev, variant=args.config, all_reduce=all_reduce,
                          all_gather=all_gather)
 
+    model.fuse = args.config == "int4" and not args.no_fuse
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()
     graph = None
@@ -601,6 +645,7 @@ def main():
             "config": {"workload": var["workload"], "batch_per_gpu": args.batch,
                        "context": args.ctx, "layers": args.layers,
                        "kv_cache": ("fp8-e4m3" if model.kv_dtype == "fp8" else "fp16") + " block 16", "hip_graph": graph is not None,
+                       "fused_consumers": bool(model.fuse),
                        "parallelism": (f"tp{tp} (one model over {tp} ranks, RCCL all-reduce in the captured step)" if tp > 0
                                        else f"dp{world} (independent TP=1 replicas)")},
             "roofline": roof,

@@ -146,6 +146,33 @@ int nmx_gptq_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b
                          int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits, int num_groups,
                          int is_k_full, int dtype, nmx_stream_t stream);
 
+/* gptq_marlin_gemm with the split-K reduction deferred to the op that consumes the output (no reference counterpart:
+ * the reference runs gptq_marlin_gemm, then the next op, as two passes over the activation). When the dispatch splits K
+ * across workgroups, the fp32 slabs [*splits_out, size_m, size_n] are left at the start of `scratch`, c is untouched and
+ * one of the *_splitk consumers below sums them while it loads its rows; *splits_out == 1 means c holds the result.
+ * Results of GEMM + consumer are bit-identical to nmx_gptq_marlin_gemm followed by the plain op. */
+int nmx_gptq_marlin_gemm_deferred(const void* a, const int32_t* b_q_weight, const void* b_scales, const int32_t* g_idx,
+                                  const int32_t* perm, void* c, int64_t workspace_numel, void* scratch,
+                                  int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits,
+                                  int num_groups, int is_k_full, int dtype, int* splits_out, nmx_stream_t stream);
+/* fused_add_rms_norm (csrc/layernorm_kernels.cu:258-291) on x = round(sum_s partial[s]): residual += x,
+ * input_out = rms_norm(residual) * weight. partial [splits, num_tokens, hidden] fp32, splits >= 2. */
+int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int splits, void* residual, const void* weight,
+                                  float epsilon, int num_tokens, int hidden_size, int dtype, nmx_stream_t stream);
+/* silu_and_mul (csrc/activation_kernels.cu:12-30) on x = round(sum_s partial[s]); partial [splits, num_tokens, 2 d]. */
+int nmx_silu_and_mul_splitk(void* out, const float* partial, int splits, int num_tokens, int d, int dtype,
+                            nmx_stream_t stream);
+/* rotary_embedding (NeoX, rot_dim == head_size; csrc/pos_encoding_kernels.cu:10-96) on the q and k heads of a fused
+ * qkv row [q heads | k heads | v heads] followed by reshape_and_cache (csrc/cache_kernels.cu:153-278) of the rotated k
+ * and the v heads, in ONE launch. splits == 1: qkv [num_tokens, (H + 2 KVH) * D] is rotated in place; splits >= 2: the
+ * row is round(sum_s partial[s]) and written to qkv. cos_sin_cache [max_pos, D]; caches / slot_mapping / kv_dtype /
+ * kv_scale as nmx_reshape_and_cache. */
+int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, const float* partial, int splits,
+                               const void* cos_sin_cache, void* key_cache, void* value_cache,
+                               const int64_t* slot_mapping, int num_tokens, int num_heads, int num_kv_heads,
+                               int head_size, int block_size, int dtype, int kv_dtype, float kv_scale,
+                               nmx_stream_t stream);
+
 /* marlin_gemm (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136): int4, fp16, groups of 128 or
  * channel-wise, weights Marlin-packed in the checkpoint. */
 int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,

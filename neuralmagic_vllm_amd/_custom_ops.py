@@ -485,6 +485,90 @@ def marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tenso
     return c
 
 
+# ---------------------------------------------------------------------------------------------------------
+# fused decode path (extensions, not part of vllm._custom_ops): the split-K reduction of a Marlin GEMM is deferred to the
+# op that consumes its output. Every combination is bit-identical to the plain op sequence; the plain ops stay available.
+# ---------------------------------------------------------------------------------------------------------
+class DeferredGemm:
+    """Output of gptq_marlin_gemm_deferred: `out` [M, N] (valid iff splits == 1), else `partial` [splits, M, N] fp32."""
+    __slots__ = ("out", "partial", "splits")
+
+    def __init__(self, out, partial, splits):
+        self.out, self.partial, self.splits = out, partial, splits
+
+    def materialize(self) -> torch.Tensor:
+        """Plain reduction (what the reduce launch would have produced), for consumers without a fused form."""
+        if self.splits > 1:
+            self.out.copy_(self.partial.sum(dim=0))
+            self.splits = 1
+        return self.out
+
+
+def gptq_marlin_gemm_deferred(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor, g_idx: torch.Tensor,
+                              perm: torch.Tensor, workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int,
+                              size_k: int, is_k_full: bool) -> DeferredGemm:
+    _dev(a)
+    if a.dim() != 2 or a.shape[0] != size_m or a.shape[1] != size_k:
+        raise RuntimeError(f"Shape mismatch: a.size = {tuple(a.shape)}, size_m = {size_m}, size_k = {size_k}")
+    if not a.is_contiguous():
+        raise RuntimeError("A is not contiguous")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return DeferredGemm(c, None, 1)
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    splits = c_int(1)
+    has_idx = g_idx is not None and g_idx.numel() > 0
+    _lib.check(_lib.lib().nmx_gptq_marlin_gemm_deferred(
+        _p(a), _p(b_q_weight), _p(b_scales), _p(g_idx if has_idx else None), _p(perm if has_idx else None), _p(c),
+        c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n), c_int(size_k),
+        c_int(num_bits), c_int(b_scales.shape[0]), c_int(int(is_k_full)), c_int(_dt(a)), ctypes.byref(splits), _stream(a)))
+    if splits.value > 1:
+        partial = scratch[:splits.value * size_m * size_n * 4].view(torch.float32).view(splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, splits.value)
+    return DeferredGemm(c, None, 1)
+
+
+def fused_add_rms_norm_splitk(g: DeferredGemm, residual: torch.Tensor, weight: torch.Tensor, epsilon: float) -> torch.Tensor:
+    """fused_add_rms_norm(g.out, residual, ...) on the deferred GEMM output; returns the normed tensor (g.out's storage)."""
+    if g.splits == 1:
+        fused_add_rms_norm(g.out, residual, weight, epsilon)
+        return g.out
+    out = g.out
+    _lib.check(_lib.lib().nmx_fused_add_rms_norm_splitk(_p(out), _p(g.partial), c_int(g.splits), _p(residual), _p(weight),
+                                                        c_f(epsilon), c_int(out.shape[0]), c_int(out.shape[1]),
+                                                        c_int(_dt(out)), _stream(out)))
+    return out
+
+
+def silu_and_mul_splitk(out: torch.Tensor, g: DeferredGemm) -> None:
+    if g.splits == 1:
+        silu_and_mul(out, g.out)
+        return
+    _lib.check(_lib.lib().nmx_silu_and_mul_splitk(_p(out), _p(g.partial), c_int(g.splits), c_int(out.shape[0]),
+                                                  c_int(out.shape[1]), c_int(_dt(out)), _stream(out)))
+
+
+def rope_reshape_and_cache(positions: torch.Tensor, g, num_heads: int, num_kv_heads: int, head_size: int,
+                           cos_sin_cache: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                           slot_mapping: torch.Tensor, kv_cache_dtype: str, kv_scale: float) -> torch.Tensor:
+    """rotary_embedding (NeoX, whole head) on q / k of the fused qkv row + reshape_and_cache of k / v in one launch.
+    g: a DeferredGemm or a plain [T, (H + 2 KVH) * D] tensor. Returns the qkv tensor (q, k rotated)."""
+    if not isinstance(g, DeferredGemm):
+        g = DeferredGemm(g, None, 1)
+    qkv = g.out
+    if not qkv.is_contiguous() or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * head_size:
+        raise RuntimeError("rope_reshape_and_cache: qkv must be a contiguous [T, (H + 2 KVH) * D] tensor")
+    if cos_sin_cache.shape[1] != head_size or cos_sin_cache.dtype != qkv.dtype:
+        raise RuntimeError("rope_reshape_and_cache: rotary over the whole head, cache in the activation dtype")
+    block_size = value_cache.shape[3]
+    _lib.check(_lib.lib().nmx_rope_reshape_and_cache(
+        _p(positions), _p(qkv), _p(g.partial), c_int(g.splits), _p(cos_sin_cache), _p(key_cache), _p(value_cache),
+        _p(slot_mapping), c_int(qkv.shape[0]), c_int(num_heads), c_int(num_kv_heads), c_int(head_size), c_int(block_size),
+        c_int(_dt(qkv)), c_int(_kv(kv_cache_dtype)), c_f(kv_scale), _stream(qkv)))
+    g.splits = 1
+    return qkv
+
+
 def gptq_marlin_24_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_meta: torch.Tensor, b_scales: torch.Tensor,
                         workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
     # checks mirror csrc/quantization/marlin/sparse/marlin_24_cuda_kernel.cu:1024-1082

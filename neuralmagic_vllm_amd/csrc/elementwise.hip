@@ -268,6 +268,165 @@ int launch_act(void* out, const void* in, int num_tokens, int d, int act, bool g
   return NMX_OK;
 }
 
+
+// ---- consumers of DEFERRED split-K partial sums ---------------------------------------------------------------------
+// A Marlin-family GEMM that splits K across workgroups leaves fp32 slabs partial[s][row][col]; instead of a reduce launch
+// (read the slabs, write fp16, then the next element-wise op reads that again) the op that consumes the GEMM output sums
+// them while loading its row: one dependent launch and one fp16 round trip less per GEMM. The sum runs in the order of
+// splitk_reduce_kernel (s = 0, 1, ...) and is rounded to scalar_t before any further arithmetic, so every result is
+// bit-identical to the unfused op sequence.
+template <typename T>
+__device__ __forceinline__ void sum_partials8(const float* __restrict__ partial, int splits, int64_t slab, int64_t off, T (&e)[8]) {
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  for (int sidx = 0; sidx < splits; ++sidx) {
+    a0 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off);
+    a1 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off + 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    e[j] = Scalar<T>::from_f32(a0[j]);
+    e[4 + j] = Scalar<T>::from_f32(a1[j]);
+  }
+}
+
+// fused_add_rms_norm on x = round(sum_s partial[s]): residual += x; out = norm(residual) * weight (layernorm_kernels.cu:258-291)
+template <typename T, int VPT>
+__global__ void rms_norm_splitk_kernel(T* __restrict__ out, const float* __restrict__ partial, int splits, T* __restrict__ residual,
+                                       const T* __restrict__ weight, float eps, int hidden, int64_t slab) {
+  __shared__ float smem[17];
+  const int64_t row = (int64_t)blockIdx.x * hidden;
+  const int nvec = hidden / 8;
+  union V { u32x4 u; T e[8]; };
+  V x[VPT], w[VPT];
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = threadIdx.x + k * blockDim.x;
+    if (v < nvec) w[k].u = *reinterpret_cast<const u32x4*>(weight + v * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = threadIdx.x + k * blockDim.x;
+    if (v < nvec) {
+      sum_partials8<T>(partial, splits, slab, row + v * 8, x[k].e);
+      V r;
+      r.u = *reinterpret_cast<const u32x4*>(residual + row + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[k].e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) + Scalar<T>::to_f32(r.e[j]));
+      *reinterpret_cast<u32x4*>(residual + row + v * 8) = x[k].u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = Scalar<T>::to_f32(x[k].e[j]);
+        var += f * f;
+      }
+    }
+  }
+  var = block_sum(var, smem);
+  const float sc = rsqrtf(var / (float)hidden + eps);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = threadIdx.x + k * blockDim.x;
+    if (v < nvec) {
+      V o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * sc), w[k].e[j]);
+      *reinterpret_cast<u32x4*>(out + row + v * 8) = o.u;
+    }
+  }
+}
+
+// silu_and_mul on x = round(sum_s partial[s]) (activation_kernels.cu:12-30)
+template <typename T>
+__global__ void silu_and_mul_splitk_kernel(T* __restrict__ out, const float* __restrict__ partial, int splits, int d, int64_t slab) {
+  const int64_t tok = blockIdx.x;
+  union V { u32x4 u; T e[8]; };
+  for (int v = threadIdx.x; v < d / 8; v += blockDim.x) {
+    V a, b, o;
+    sum_partials8<T>(partial, splits, slab, tok * 2 * d + v * 8, a.e);
+    sum_partials8<T>(partial, splits, slab, tok * 2 * d + d + v * 8, b.e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(act_fn<T, ACT_SILU>(a.e[j]), b.e[j]);
+    *reinterpret_cast<u32x4*>(out + tok * d + v * 8) = o.u;
+  }
+}
+
+// rotary_embedding (NeoX, rot_dim == head_size) on the q and k heads of a fused qkv row + reshape_and_cache of the
+// (rotated) k and v heads, in one pass over the row (pos_encoding_kernels.cu:10-96, cache_kernels.cu:153-278); the row
+// comes from fp16 / bf16 qkv (splits == 1, rotated in place) or from split-K partial sums (written to qkv once).
+// One thread = 8 consecutive rotary indices of one head: the x run and the y run (8 elements each).
+template <typename T, int KV>
+__global__ void rope_cache_kernel(const int64_t* __restrict__ positions, T* __restrict__ qkv, const float* __restrict__ partial,
+                                  int splits, int64_t slab, const T* __restrict__ cos_sin_cache, void* __restrict__ key_cache,
+                                  void* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int num_heads,
+                                  int num_kv_heads, int head_size, int block_size, float kv_scale) {
+  using cache_t = typename std::conditional<KV == NMX_KV_AUTO, T, uint8_t>::type;
+  constexpr int X = 16 / sizeof(cache_t);  // elements per 16-byte K chunk
+  const int64_t tok = blockIdx.x;
+  const int embed = head_size / 2, vper = embed / 8;
+  const int heads = num_heads + 2 * num_kv_heads;
+  const int64_t row = tok * (int64_t)heads * head_size;
+  const int64_t pos = positions[tok];
+  const int64_t slot = slot_mapping[tok];
+  const int64_t block_idx = slot / block_size, block_off = slot % block_size;
+  const T* cache = cos_sin_cache + pos * head_size;
+  union V { u32x4 u; T e[8]; };
+  for (int i = threadIdx.x; i < heads * vper; i += blockDim.x) {
+    const int head = i / vper, ro = (i % vper) * 8;
+    const int64_t base = row + (int64_t)head * head_size;
+    V x, y;
+    if (splits > 1) {
+      sum_partials8<T>(partial, splits, slab, base + ro, x.e);
+      sum_partials8<T>(partial, splits, slab, base + embed + ro, y.e);
+    } else {
+      x.u = *reinterpret_cast<const u32x4*>(qkv + base + ro);
+      y.u = *reinterpret_cast<const u32x4*>(qkv + base + embed + ro);
+    }
+    const bool is_v = head >= num_heads + num_kv_heads;
+    if (!is_v) {
+      V c, sn, ox, oy;
+      c.u = *reinterpret_cast<const u32x4*>(cache + ro);
+      sn.u = *reinterpret_cast<const u32x4*>(cache + embed + ro);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ox.e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(x.e[j], c.e[j])) - Scalar<T>::to_f32(rnd_mul<T>(y.e[j], sn.e[j])));
+        oy.e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(y.e[j], c.e[j])) + Scalar<T>::to_f32(rnd_mul<T>(x.e[j], sn.e[j])));
+      }
+      x = ox;
+      y = oy;
+    }
+    if (!is_v || splits > 1) {
+      *reinterpret_cast<u32x4*>(qkv + base + ro) = x.u;
+      *reinterpret_cast<u32x4*>(qkv + base + embed + ro) = y.u;
+    }
+    if (head < num_heads || slot < 0) continue;  // q heads / padding tokens: nothing to cache
+    const int kvh = is_v ? head - num_heads - num_kv_heads : head - num_heads;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const V& val = half == 0 ? x : y;
+      const int d0 = half == 0 ? ro : embed + ro;
+      if (!is_v) {
+        cache_t* kc = reinterpret_cast<cache_t*>(key_cache) +
+                      (((block_idx * num_kv_heads + kvh) * (head_size / X) + d0 / X) * block_size + block_off) * X + d0 % X;
+        if constexpr (KV == NMX_KV_AUTO) {
+          *reinterpret_cast<u32x4*>(kc) = val.u;
+        } else {
+          union { u32x2 u; uint8_t b[8]; } q;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) q.b[j] = f32_to_fp8_sat<KV>(Scalar<T>::to_f32(val.e[j]) / kv_scale);
+          *reinterpret_cast<u32x2*>(kc) = q.u;
+        }
+      } else {
+        cache_t* vc = reinterpret_cast<cache_t*>(value_cache) + ((block_idx * num_kv_heads + kvh) * head_size + d0) * block_size + block_off;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if constexpr (KV == NMX_KV_AUTO) vc[(int64_t)j * block_size] = val.e[j];
+          else vc[(int64_t)j * block_size] = f32_to_fp8_sat<KV>(Scalar<T>::to_f32(val.e[j]) / kv_scale);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 #define NMX_DISPATCH_DT(dtype, CALL)                                                     \
@@ -339,4 +498,77 @@ extern "C" int nmx_activation(void* out, const void* input, int num_tokens, int 
                               nmx_stream_t stream) {
   if (num_tokens == 0 || d == 0) return NMX_OK;
   NMX_DISPATCH_DT(dtype, launch_act<T>(out, input, num_tokens, d, act, false, (hipStream_t)stream));
+}
+
+// ---- fused consumers of deferred split-K partials (no reference counterpart: the reference runs the ops one by one;
+//      results are bit-identical to nmx_fused_add_rms_norm / nmx_act_and_mul / nmx_rotary_embedding + nmx_reshape_and_cache
+//      applied to the reduced GEMM output) -----------------------------------------------------------------------------
+extern "C" int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int splits, void* residual,
+                                             const void* weight, float epsilon, int num_tokens, int hidden_size, int dtype,
+                                             nmx_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "fused_add_rms_norm_splitk: fp16 / bf16 only");
+  NMX_CHECK(splits >= 2 && partial != nullptr, NMX_ERR_INVALID_ARG, "fused_add_rms_norm_splitk needs >= 2 partial slabs");
+  NMX_CHECK(hidden_size % 8 == 0 && hidden_size / 8 <= 2048 &&
+                (((uintptr_t)input_out | (uintptr_t)partial | (uintptr_t)residual | (uintptr_t)weight) % 16 == 0),
+            NMX_ERR_INVALID_ARG, "fused_add_rms_norm_splitk: hidden %% 8 == 0 (<= 16384) and 16-byte aligned operands");
+  const int nvec = hidden_size / 8;
+  int threads = std::min(1024, ((nvec + 63) / 64) * 64);
+  if (nvec > 256) threads = std::min(1024, ((nvec / 2 + 63) / 64) * 64);
+  const int vpt = (nvec + threads - 1) / threads;
+  const int64_t slab = (int64_t)num_tokens * hidden_size;
+#define NMX_RS(T, V) rms_norm_splitk_kernel<T, V><<<num_tokens, threads, 0, stream>>>((T*)input_out, partial, splits, (T*)residual, (const T*)weight, epsilon, hidden_size, slab)
+  if (dtype == NMX_F16) { if (vpt == 1) NMX_RS(f16, 1); else NMX_RS(f16, 2); }
+  else { if (vpt == 1) NMX_RS(bf16, 1); else NMX_RS(bf16, 2); }
+#undef NMX_RS
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+extern "C" int nmx_silu_and_mul_splitk(void* out, const float* partial, int splits, int num_tokens, int d, int dtype,
+                                       nmx_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (num_tokens == 0 || d == 0) return NMX_OK;
+  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "silu_and_mul_splitk: fp16 / bf16 only");
+  NMX_CHECK(splits >= 2 && partial != nullptr && d % 8 == 0 && (((uintptr_t)out | (uintptr_t)partial) % 16 == 0),
+            NMX_ERR_INVALID_ARG, "silu_and_mul_splitk: >= 2 slabs, d %% 8 == 0, 16-byte aligned operands");
+  const int threads = std::min(1024, std::max(64, ((d / 8 + 63) / 64) * 64));
+  const int64_t slab = (int64_t)num_tokens * 2 * d;
+  if (dtype == NMX_F16) silu_and_mul_splitk_kernel<f16><<<num_tokens, threads, 0, stream>>>((f16*)out, partial, splits, d, slab);
+  else silu_and_mul_splitk_kernel<bf16><<<num_tokens, threads, 0, stream>>>((bf16*)out, partial, splits, d, slab);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+extern "C" int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, const float* partial, int splits,
+                                          const void* cos_sin_cache, void* key_cache, void* value_cache,
+                                          const int64_t* slot_mapping, int num_tokens, int num_heads, int num_kv_heads,
+                                          int head_size, int block_size, int dtype, int kv_dtype, float kv_scale,
+                                          nmx_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "rope_reshape_and_cache: fp16 / bf16 only");
+  NMX_CHECK(head_size % 16 == 0 && num_heads > 0 && num_kv_heads > 0, NMX_ERR_INVALID_ARG,
+            "rope_reshape_and_cache: head_size %% 16 == 0 (NeoX rotary over the whole head)");
+  NMX_CHECK((splits == 1) || (splits >= 2 && partial != nullptr), NMX_ERR_INVALID_ARG, "bad split count %d", splits);
+  NMX_CHECK((((uintptr_t)qkv | (uintptr_t)partial | (uintptr_t)cos_sin_cache | (uintptr_t)key_cache) % 16 == 0), NMX_ERR_INVALID_ARG,
+            "rope_reshape_and_cache: operands must be 16-byte aligned");
+  const int heads = num_heads + 2 * num_kv_heads;
+  const int nvec = heads * (head_size / 16);
+  const int threads = std::min(512, std::max(64, ((nvec + 63) / 64) * 64));
+  const int64_t slab = (int64_t)num_tokens * heads * head_size;
+#define NMX_RC(T, KVC) rope_cache_kernel<T, KVC><<<num_tokens, threads, 0, stream>>>(positions, (T*)qkv, partial, splits, slab, (const T*)cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads, head_size, block_size, kv_scale)
+#define NMX_RC_T(T)                                                                       \
+  switch (kv_dtype) {                                                                     \
+    case NMX_KV_AUTO: NMX_RC(T, NMX_KV_AUTO); break;                                      \
+    case NMX_KV_FP8_E4M3: NMX_RC(T, NMX_KV_FP8_E4M3); break;                              \
+    case NMX_KV_FP8_E5M2: NMX_RC(T, NMX_KV_FP8_E5M2); break;                              \
+    default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "unsupported kv cache dtype %d", kv_dtype); \
+  }
+  if (dtype == NMX_F16) { NMX_RC_T(f16) } else { NMX_RC_T(bf16) }
+#undef NMX_RC_T
+#undef NMX_RC
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
 }

@@ -7,7 +7,7 @@ namespace {
 int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales, const int32_t* g_idx,
                   const int32_t* perm, void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes,
                   int size_m, int size_n, int size_k, int kind, int num_groups, int is_k_full, int dtype,
-                  hipStream_t stream) {
+                  hipStream_t stream, int defer_reduce = 0, int* splits_out = nullptr) {
   // checks mirror gptq_marlin.cu:1741-1843
   NMX_CHECK(size_k % 16 == 0, NMX_ERR_INVALID_ARG, "size_k = %d is not divisible by tile_size = 16", size_k);
   NMX_CHECK(size_n % 64 == 0, NMX_ERR_INVALID_ARG, "size_n = %d is not divisible by min_thread_n = 64", size_n);
@@ -20,6 +20,8 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   GemmParams p;
   p.a = a; p.b = b_q_weight; p.meta = nullptr; p.scales = b_scales; p.g_idx = g_idx; p.perm = perm; p.c = c; p.partial = nullptr;
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.k_splits = 1; p.slow_act_order = 0;
+  p.defer_reduce = defer_reduce;
+  if (splits_out != nullptr) *splits_out = 1;
   if (has_act_order) {
     if (is_k_full) {
       NMX_CHECK(num_groups > 1, NMX_ERR_INVALID_ARG, "For act_order, num_groups must be > 1");
@@ -42,15 +44,18 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
             NMX_ERR_INVALID_ARG, "marlin gemm: operands must be 16-byte aligned");
   if (size_m == 0 || size_n == 0) return NMX_OK;
 
+  int rc;
 #define NMX_DISPATCH_KIND(T)                                                                   \
   switch (kind) {                                                                              \
-    case W_INT4: return launch_skinny<T, W_INT4>(p, scratch, scratch_bytes, stream);           \
-    case W_INT8: return launch_skinny<T, W_INT8>(p, scratch, scratch_bytes, stream);           \
-    default: return launch_skinny<T, W_FP8>(p, scratch, scratch_bytes, stream);                \
+    case W_INT4: rc = launch_skinny<T, W_INT4>(p, scratch, scratch_bytes, stream); break;      \
+    case W_INT8: rc = launch_skinny<T, W_INT8>(p, scratch, scratch_bytes, stream); break;      \
+    default: rc = launch_skinny<T, W_FP8>(p, scratch, scratch_bytes, stream); break;           \
   }
   if (dtype == NMX_F16) { NMX_DISPATCH_KIND(f16) }
   else { NMX_DISPATCH_KIND(bf16) }
 #undef NMX_DISPATCH_KIND
+  if (splits_out != nullptr) *splits_out = p.k_splits;  // > 1 only when the reduce was deferred to the consumer
+  return rc;
 }
 
 }  // namespace
@@ -95,6 +100,22 @@ extern "C" int nmx_gptq_marlin_gemm(const void* a, const int32_t* b_q_weight, co
   return marlin_common(a, b_q_weight, b_scales, g_idx, perm, c, workspace_numel, scratch, scratch_bytes, size_m,
                        size_n, size_k, num_bits == 4 ? W_INT4 : W_INT8, num_groups, is_k_full, dtype,
                        (hipStream_t)stream);
+}
+
+// gptq_marlin_gemm with the split-K reduction DEFERRED to the consumer: when the dispatch splits K across workgroups the
+// fp32 slabs [splits, size_m, size_n] stay at the start of `scratch`, *splits_out says how many, c is left untouched, and
+// nmx_fused_add_rms_norm_splitk / nmx_silu_and_mul_splitk / nmx_rope_reshape_and_cache sum them while loading their rows.
+// *splits_out == 1: c holds the result as usual.
+extern "C" int nmx_gptq_marlin_gemm_deferred(const void* a, const int32_t* b_q_weight, const void* b_scales,
+                                             const int32_t* g_idx, const int32_t* perm, void* c, int64_t workspace_numel,
+                                             void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k,
+                                             int num_bits, int num_groups, int is_k_full, int dtype, int* splits_out,
+                                             nmx_stream_t stream) {
+  NMX_CHECK(num_bits == 4 || num_bits == 8, NMX_ERR_INVALID_ARG, "num_bits must be 4 or 8. Got = %d", num_bits);
+  NMX_CHECK(splits_out != nullptr, NMX_ERR_INVALID_ARG, "splits_out is null");
+  return marlin_common(a, b_q_weight, b_scales, g_idx, perm, c, workspace_numel, scratch, scratch_bytes, size_m,
+                       size_n, size_k, num_bits == 4 ? W_INT4 : W_INT8, num_groups, is_k_full, dtype,
+                       (hipStream_t)stream, 1, splits_out);
 }
 
 extern "C" int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,

@@ -219,6 +219,7 @@ struct GemmParams {
   int num_groups, group_size;  // group_size = K for channel-wise
   int k_splits;
   int slow_act_order;      // act-order with partial K: per-row scale lookup
+  int defer_reduce;        // k_splits > 1: leave the fp32 slabs in `partial` for the consumer (no reduce launch)
 };
 
 // ---- the GEMM kernel -------------------------------------------------------------------------------------------
@@ -1546,7 +1547,7 @@ int launch_large(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
   }
 #undef NMX_LAUNCH_LARGE
   NMX_LAUNCH_CHECK();
-  if (p.k_splits > 1) {
+  if (p.k_splits > 1 && !p.defer_reduce) {
     const int64_t mn4 = (int64_t)p.M * p.N / 4;
     splitk_reduce_kernel<scalar_t><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(
         reinterpret_cast<scalar_t*>(p.c), p.partial, mn4, p.k_splits);
@@ -1641,7 +1642,7 @@ int launch_decode(GemmParams& p, const DecodeCfg& cfg, void* scratch, int64_t sc
       rc = ws ? launch_decode_cfg<scalar_t, 2, 4, true>(p, stream) : launch_decode_cfg<scalar_t, 2, 4, false>(p, stream);
   }
   if (rc != NMX_OK) return rc;
-  if (p.k_splits > 1) {
+  if (p.k_splits > 1 && !p.defer_reduce) {
     const int64_t mn4 = (int64_t)p.M * p.N / 4;
     splitk_reduce_kernel<scalar_t><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(
         reinterpret_cast<scalar_t*>(p.c), p.partial, mn4, p.k_splits);
@@ -1670,7 +1671,10 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
       call.a = p.a; call.b = p.b; call.scales = p.scales; call.c = p.c; call.scratch = scratch; call.scratch_bytes = scratch_bytes;
       call.M = p.M; call.N = p.N; call.K = p.K; call.num_groups = p.num_groups; call.group_size = p.group_size;
       call.kind = KIND; call.is_bf16 = __is_same(scalar_t, bf16) ? 1 : 0;
-      return nmx_wide_launch(call, wc, stream);
+      call.defer_reduce = p.defer_reduce;
+      const int rc = nmx_wide_launch(call, wc, stream);
+      p.k_splits = call.splits_done;
+      return rc;
     }
     if (use_large(p, false)) return launch_large<scalar_t, KIND>(p, scratch, scratch_bytes, stream);
   }
@@ -1693,7 +1697,7 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
   else if (p.num_groups > 1) rc = launch_mode<scalar_t, KIND, 1, SP>(p, cfg, stream);
   else rc = launch_mode<scalar_t, KIND, 0, SP>(p, cfg, stream);
   if (rc != NMX_OK) return rc;
-  if (p.k_splits > 1) {
+  if (p.k_splits > 1 && !p.defer_reduce) {
     const int64_t mn4 = (int64_t)p.M * p.N / 4;
     splitk_reduce_kernel<scalar_t><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(
         reinterpret_cast<scalar_t*>(p.c), p.partial, mn4, p.k_splits);

@@ -576,11 +576,12 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
   return true;
 }
 
-int nmx_wide_launch(const NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream) {
+int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream) {
   GemmParams p;
   p.a = call.a; p.b = call.b; p.meta = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
   p.M = call.M; p.N = call.N; p.K = call.K; p.num_groups = call.num_groups; p.group_size = call.group_size;
   p.slow_act_order = 0;
+  p.defer_reduce = call.defer_reduce;
   p.k_splits = cfg.splits;
   if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to the splits that fit
     const int64_t per = (int64_t)p.M * p.N * sizeof(float);
@@ -602,7 +603,8 @@ int nmx_wide_launch(const NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t 
 #undef NMX_WIDE_KIND
 #endif
   if (rc != NMX_OK) return rc;
-  if (p.k_splits > 1) {
+  call.splits_done = p.k_splits;
+  if (p.k_splits > 1 && !p.defer_reduce) {
     const int64_t mn4 = (int64_t)p.M * p.N / 4;
     if (call.is_bf16)
       splitk_reduce_kernel<bf16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<bf16*>(p.c), p.partial, mn4, p.k_splits);

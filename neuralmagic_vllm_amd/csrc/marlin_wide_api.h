@@ -15,6 +15,8 @@ struct NmxWideCall {
   int num_groups, group_size;
   int kind;               // WeightKind
   int is_bf16;
+  int defer_reduce;       // leave split-K partials in scratch (no reduce launch)
+  int splits_done;        // out: K splits the launch used
 };
 
 // tile configuration of marlin_wide_kernel: wm x wn x wk waves, `splits` K splits across workgroups
@@ -22,4 +24,4 @@ struct NmxWideCfg { int wm, wn, wk, splits; };
 
 // true when the wide kernel handles this problem (M large enough, plain layout); fills the configuration
 __attribute__((visibility("hidden"))) bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg);
-__attribute__((visibility("hidden"))) int nmx_wide_launch(const NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream);
+__attribute__((visibility("hidden"))) int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream);

@@ -239,10 +239,55 @@ def gen_elementwise():
     print("wrote elementwise")
 
 
+def gen_opt125m():
+    """BASELINE configs[0] geometry (OPT-125m: 12 MHA heads x 64, hidden 768, block 16, bf16 - the dtype the reference's
+    CPU backend decodes it in): paged_attention_v1 / v2 and reshape_and_cache of the reference CPU backend
+    (csrc/cpu/attention.cpp:222-439, csrc/cpu/cache.cpp)."""
+    from oracle import build_ref
+    assert build_ref.build() and build_ref.load()
+    ops, cops = torch.ops.nmref_cpu, torch.ops.nmref_cpu_cache_ops
+    torch.manual_seed(125)
+    random.seed(125)
+    dtype, S, H, D, NB, BS, max_len = torch.bfloat16, 5, 12, 64, 20, 16, 600
+    scale = float(D**-0.5)
+    q = torch.empty(S, H, D, dtype=dtype).uniform_(-scale, scale)
+    kc = torch.empty(NB, H, D // 8, BS, 8, dtype=dtype).uniform_(-scale, scale)
+    vc = torch.empty(NB, H, D, BS, dtype=dtype).uniform_(-scale, scale)
+    seq_lens = [1, 16, 513, 130, max_len]
+    mb = (max_len + BS - 1) // BS
+    bt = torch.tensor([[random.randint(0, NB - 1) for _ in range(mb)] for _ in range(S)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    out1, out2 = torch.empty_like(q), torch.empty_like(q)
+    ops.paged_attention_v1(out1, q, kc, vc, H, scale, bt, sl, BS, max_len, None, "auto", 1.0, 0, 0, 0, 64, 0)
+    P = (max_len + 511) // 512
+    tmp = torch.empty(S, H, P, D, dtype=dtype)
+    es, ml = torch.empty(S, H, P, dtype=torch.float32), torch.empty(S, H, P, dtype=torch.float32)
+    ops.paged_attention_v2(out2, es, ml, tmp, q, kc, vc, H, scale, bt, sl, BS, max_len, None, "auto", 1.0, 0, 0, 0, 64, 0)
+    np.savez_compressed(os.path.join(HERE, "attn_bf16_opt125m.npz"), q=bits(q), k_cache=bits(kc), v_cache=bits(vc),
+                        block_tables=bt.numpy(), seq_lens=sl.numpy(), out_v1=bits(out1), out_v2=bits(out2),
+                        scale=np.float32(scale), num_kv_heads=np.int32(H), max_seq_len=np.int32(max_len), dtype="bfloat16")
+    T = 9
+    qkv = torch.randn(T, 3, H, D, dtype=dtype)
+    NB2 = 4
+    kc2, vc2 = torch.randn(NB2, H, D // 8, BS, 8, dtype=dtype), torch.randn(NB2, H, D, BS, dtype=dtype)
+    slots = torch.tensor(random.sample(range(NB2 * BS), T), dtype=torch.int64)
+    slots[4] = -1
+    k_in, v_in = kc2.clone(), vc2.clone()
+    cops.reshape_and_cache(qkv[:, 1], qkv[:, 2], kc2, vc2, slots, "auto", 1.0)
+    np.savez_compressed(os.path.join(HERE, "reshape_and_cache_bf16_opt125m.npz"), qkv=bits(qkv), k_cache_in=bits(k_in),
+                        v_cache_in=bits(v_in), slot_mapping=slots.numpy(), k_cache_out=bits(kc2), v_cache_out=bits(vc2),
+                        dtype="bf16")
+    print("wrote attn_bf16_opt125m, reshape_and_cache_bf16_opt125m")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "elementwise":
         gen_elementwise()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "opt125m":
+        gen_opt125m()
+        sys.exit(0)
     gen_quant()
     gen_attention_cache()
+    gen_opt125m()
     gen_elementwise()

@@ -49,7 +49,7 @@ def run_oracle(version, q, kc, vc, kvh, scale, bt, sl, block_size, max_len, alib
     return out
 
 
-@pytest.mark.parametrize("name", ["attn_bf16_gqa", "attn_bf16_alibi_mha", "attn_f32_gqa"])
+@pytest.mark.parametrize("name", ["attn_bf16_gqa", "attn_bf16_alibi_mha", "attn_f32_gqa", "attn_bf16_opt125m"])
 @pytest.mark.parametrize("version", ["v1", "v2"])
 def test_attention_golden(ops, name, version):
     """Outputs of the reference's own CPU backend (bf16; the reference CPU backend has no fp16)."""

@@ -17,10 +17,10 @@ def _int_view(t):
     return t.view({1: torch.uint8, 2: torch.int16, 4: torch.int32}[t.element_size()])
 
 
-@pytest.mark.parametrize("tag", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["f32", "bf16", "bf16_opt125m"])  # opt125m: BASELINE configs[0] geometry (12 x 64 heads)
 def test_reshape_and_cache_golden(ops, tag):
     g = load_golden("reshape_and_cache_" + tag)
-    dt = DTYPES[tag]
+    dt = DTYPES[tag.split("_")[0]]
     qkv = from_bits(g["qkv"], dt).to(DEV)
     kc = from_bits(g["k_cache_in"], dt).to(DEV)
     vc = from_bits(g["v_cache_in"], dt).to(DEV)

@@ -1,0 +1,129 @@
+"""Fused decode-path ops (extensions): the split-K reduction of gptq_marlin_gemm deferred into the consumer
+(fused_add_rms_norm / silu_and_mul / rotary + reshape_and_cache). Each fused path must be BIT-IDENTICAL to the plain op
+sequence on the HIP ops, and equal to the CPU oracle's unfused element-wise op applied to the same GEMM output
+(reference ops: layernorm_kernels.cu:258-291, activation_kernels.cu:12-30, pos_encoding_kernels.cu:10-96,
+cache_kernels.cu:153-278)."""
+import pytest
+import torch
+
+import oracle
+from util import seed_all
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bits(t):
+    return t.contiguous().view({1: torch.uint8, 2: torch.int16, 4: torch.int32}[t.element_size()])
+
+
+def _weights(K, N, seed):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    q = torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32, device=DEV, generator=g)
+    s = (torch.rand(K // 128, N, device=DEV, generator=g) * 0.004 + 0.002).to(torch.float16)
+    return q, s
+
+
+def _gemm_pair(ops, a, q, s, K, N):
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
+    plain = ops.gptq_marlin_gemm(a, q, s, e, e, ws, 4, a.shape[0], N, K, True)
+    g = ops.gptq_marlin_gemm_deferred(a, q, s, e, e, ws, 4, a.shape[0], N, K, True)
+    return plain, g
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 33, 64, 256])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (14336, 4096)])
+def test_deferred_gemm_add_rms_norm(ops, M, K, N):
+    seed_all(M)
+    q, s = _weights(K, N, 1)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV)
+    plain, g = _gemm_pair(ops, a, q, s, K, N)
+    if M <= 64:
+        assert g.splits > 1, "these shapes split K at small M: the fused form must be the one under test"
+    res0 = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    w = (torch.rand(N, device=DEV) + 0.5).half()
+    res_a, res_b = res0.clone(), res0.clone()
+    ops.fused_add_rms_norm(plain, res_a, w, 1e-5)
+    gemm_out = g.partial.sum(0).half() if g.splits > 1 else g.out.clone()
+    fused = ops.fused_add_rms_norm_splitk(g, res_b, w, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(fused), _bits(plain)) and torch.equal(_bits(res_a), _bits(res_b))
+    # oracle's unfused op on the same GEMM output
+    x_o, r_o = gemm_out.cpu(), res0.cpu()
+    oracle.fused_add_rms_norm(x_o, r_o, w.cpu(), 1e-5)
+    assert torch.equal(_bits(fused.cpu()), _bits(x_o)) and torch.equal(_bits(res_b.cpu()), _bits(r_o))
+
+
+@pytest.mark.parametrize("M", [1, 16, 48, 64])
+def test_deferred_gemm_silu_and_mul(ops, M):
+    K, N = 4096, 28672
+    seed_all(M)
+    q, s = _weights(K, N, 2)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV)
+    plain, g = _gemm_pair(ops, a, q, s, K, N)
+    out_a = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
+    out_b = torch.empty_like(out_a)
+    ops.silu_and_mul(out_a, plain)
+    ops.silu_and_mul_splitk(out_b, g)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(out_a), _bits(out_b))
+    out_o = torch.empty(M, N // 2, dtype=torch.float16)
+    oracle.act_and_mul(out_o, plain.cpu(), "silu")
+    assert torch.equal(_bits(out_b.cpu()), _bits(out_o))
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 64, 200])
+@pytest.mark.parametrize("kv_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("deferred", [True, False])
+def test_rope_reshape_and_cache(ops, M, kv_dtype, deferred):
+    H, KVH, D, BS, NB = 32, 8, 128, 16, 64
+    K, N = 4096, (H + 2 * KVH) * D
+    seed_all(M + 100)
+    q, s = _weights(K, N, 3)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV)
+    plain, g = _gemm_pair(ops, a, q, s, K, N)
+    if not deferred:
+        g = plain.clone()
+    max_pos = 512
+    cos_sin = torch.randn(max_pos, D, device=DEV).half()
+    positions = torch.randint(0, max_pos, (M, ), device=DEV)
+    slots = torch.randperm(NB * BS, device=DEV)[:M].long()
+    if M > 4:
+        slots[3] = -1  # padding token: rotated like every row, not cached
+    cdt = torch.uint8 if kv_dtype == "fp8" else torch.float16
+    x = 16 if kv_dtype == "fp8" else 8
+    kc0 = torch.randint(0, 100, (NB, KVH, D // x, BS, x), device=DEV).to(cdt)
+    vc0 = torch.randint(0, 100, (NB, KVH, D, BS), device=DEV).to(cdt)
+    kv_scale = 0.05 if kv_dtype == "fp8" else 1.0
+    # plain sequence
+    kc_a, vc_a = kc0.clone(), vc0.clone()
+    qa, ka, va = plain.split([H * D, KVH * D, KVH * D], dim=-1)
+    ops.rotary_embedding(positions, qa, ka, D, cos_sin, True)
+    ops.reshape_and_cache(ka.view(-1, KVH, D), va.view(-1, KVH, D), kc_a, vc_a, slots, kv_dtype, kv_scale)
+    # fused
+    kc_b, vc_b = kc0.clone(), vc0.clone()
+    qkv = ops.rope_reshape_and_cache(positions, g, H, KVH, D, cos_sin, kc_b, vc_b, slots, kv_dtype, kv_scale)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(qkv), _bits(plain))
+    assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
+    # oracle's unfused ops on the same (unrotated) GEMM output
+    _, g2 = _gemm_pair(ops, a, q, s, K, N)
+    raw = (g2.partial.sum(0).half() if g2.splits > 1 else g2.out).cpu()
+    qo, ko, vo = raw.split([H * D, KVH * D, KVH * D], dim=-1)
+    oracle.rotary_embedding(positions.cpu(), qo, ko, D, cos_sin.cpu(), True)
+    kc_o, vc_o = kc0.cpu().clone(), vc0.cpu().clone()
+    oracle.reshape_and_cache(ko.reshape(-1, KVH, D), vo.reshape(-1, KVH, D), kc_o, vc_o, slots.cpu(), kv_dtype, kv_scale)
+    assert torch.equal(_bits(qkv.cpu()[:, :(H + KVH) * D]), _bits(torch.cat([qo, ko], dim=-1)))
+    assert torch.equal(kc_b.cpu(), kc_o) and torch.equal(vc_b.cpu(), vc_o)
+
+
+def test_deferred_materialize_matches_plain(ops):
+    K, N, M = 4096, 4096, 16
+    seed_all(9)
+    q, s = _weights(K, N, 4)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV)
+    plain, g = _gemm_pair(ops, a, q, s, K, N)
+    assert g.splits > 1
+    assert torch.equal(_bits(g.materialize()), _bits(plain))

@@ -14,7 +14,7 @@ from oracle import packing
 from util import DTYPES, from_bits, load_golden
 
 
-@pytest.mark.parametrize("name", ["attn_f32_gqa", "attn_bf16_gqa", "attn_bf16_alibi_mha"])
+@pytest.mark.parametrize("name", ["attn_f32_gqa", "attn_bf16_gqa", "attn_bf16_alibi_mha", "attn_bf16_opt125m"])
 @pytest.mark.parametrize("version", ["v1", "v2"])
 def test_attention_oracle_vs_reference_cpu(name, version):
     g = load_golden(name)
@@ -42,10 +42,10 @@ def test_attention_oracle_vs_reference_cpu(name, version):
     torch.testing.assert_close(out.float(), ref.float(), atol=atol, rtol=1e-5 if dt != torch.float32 else 1e-4)
 
 
-@pytest.mark.parametrize("tag", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["f32", "bf16", "bf16_opt125m"])
 def test_reshape_and_cache_oracle_bit_exact(tag):
     g = load_golden("reshape_and_cache_" + tag)
-    dt = DTYPES[tag]
+    dt = DTYPES[tag.split("_")[0]]
     qkv = from_bits(g["qkv"], dt)
     key, value = qkv[:, 1], qkv[:, 2]
     kc = from_bits(g["k_cache_in"], dt)

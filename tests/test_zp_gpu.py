@@ -187,3 +187,43 @@ def test_gptq_bad_bits(ops):
     s = torch.zeros(1, 64, dtype=torch.float16, device=DEV)
     with pytest.raises(RuntimeError, match="bit must be 2, 3, 4 or 8"):
         ops.gptq_gemm(a, qw, z, s, torch.empty(0, device=DEV), True, 5)
+
+
+@pytest.mark.parametrize("m", [1, 16, 48, 200])
+@pytest.mark.parametrize("bits,group", [(4, 128), (4, 64), (8, 128)])
+def test_cross_format_agreement(ops, m, bits, group):
+    """The extra pin available for the zero-point kernels (the reference holds no kernel test for them): ONE symmetric
+    fake-quant checkpoint - codes, scales and w_ref from the restatement of the reference's quantize_weights / gptq_pack,
+    which tests/test_oracle_golden.py holds bit-exact to the reference's own utilities - served through
+      (a) gptq_marlin_repack + gptq_marlin_gemm   (pinned by the reference's test_marlin_gemm.py bar and goldens),
+      (b) gptq_gemm, exllama (after gptq_shuffle) and plain entries, zero point 2^(bits-1) stored as z - 1,
+      (c) awq_gemm on the same codes in AWQ nibble order (4 bit)
+    must give the same product."""
+    seed_all(7)
+    K, N = 1024, 768
+    w = torch.randn(K, N, dtype=torch.float16)
+    a = torch.randn(m, K, dtype=torch.float16)
+    w_ref, q_w, s, _, _ = packing.quantize_weights(w, bits, group, False)
+    ref = a.float() @ w_ref.float()
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    qweight = packing.gptq_pack(q_w, bits, K, N)
+    mq = ops.gptq_marlin_repack(qweight.to(DEV), e, K, N, bits)
+    ms = packing.marlin_permute_scales(s, K, N, group)
+    ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
+    c_marlin = ops.gptq_marlin_gemm(a.to(DEV), mq, ms.to(DEV), e, e, ws, bits, m, N, K, True).float().cpu()
+    assert compute_max_diff(c_marlin, ref) < TOL
+    zeros = torch.full((K // group, N), 2**(bits - 1), dtype=torch.int32)
+    qzeros = packing.gptq_pack_zeros(zeros, bits)
+    noidx = torch.empty(0, device=DEV)
+    c_plain = ops.gptq_gemm(a.to(DEV), qweight.to(DEV), qzeros.to(DEV), s.to(DEV), noidx, False, bits).float().cpu()
+    qg = qweight.clone().to(DEV)
+    ops.gptq_shuffle(qg, e, bits)
+    c_exl = ops.gptq_gemm(a.to(DEV), qg, qzeros.to(DEV), s.to(DEV), noidx, True, bits).float().cpu()
+    for c in (c_plain, c_exl):
+        assert compute_max_diff(c, ref) < TOL
+        assert compute_max_diff(c, c_marlin) < TOL
+    if bits == 4:
+        c_awq = ops.awq_gemm(a.to(DEV), packing.awq_pack(q_w).to(DEV), s.to(DEV), packing.awq_pack(zeros).to(DEV), 8).float().cpu()
+        assert compute_max_diff(c_awq, ref) < TOL and compute_max_diff(c_awq, c_marlin) < TOL
+        deq = ops.awq_dequantize(packing.awq_pack(q_w).to(DEV), s.to(DEV), packing.awq_pack(zeros).to(DEV), 0, 0, 0).cpu()
+        assert torch.equal(deq.view(torch.int16), w_ref.view(torch.int16))  # the reference quantizer's own w_ref, bit for bit
