@@ -96,6 +96,26 @@ __device__ __forceinline__ u32x4 cvt8_fp8(u32x2 w, float scale) {
   return r;
 }
 
+// 8 fp8 bytes -> 8 scalar_t, no scale: every e4m3 / e5m2 value is exactly representable in fp16 and bf16
+template <typename scalar_t, int KV>
+__device__ __forceinline__ u32x4 cvt8_fp8_exact(u32x2 w) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f32x2 lo, hi;
+    if constexpr (KV == NMX_KV_FP8_E4M3) {
+      lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false);
+      hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+    } else {
+      lo = __builtin_amdgcn_cvt_pk_f32_bf8(w[i], false);
+      hi = __builtin_amdgcn_cvt_pk_f32_bf8(w[i], true);
+    }
+    r[2 * i] = pack2<scalar_t>(lo[0], lo[1]);
+    r[2 * i + 1] = pack2<scalar_t>(hi[0], hi[1]);
+  }
+  return r;
+}
+
 // Re-shape P from the MFMA C/D layout into the B-operand layout.
 // In : a = sub-tile 0, b = sub-tile 1; lane (g, q) holds tokens 4g..4g+3 of each (two packed dwords).
 // Out: lane (g, q) holds tokens 8(g&1)..8(g&1)+7 of sub-tile g>>1 (four packed dwords, token order).
@@ -385,6 +405,272 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
   }
 }
 
+// ---- fp8 KV cache, block_size >= 16: 64-token tiles with 16-byte loads ---------------------------------------------
+// paged_attention_kernel reads an fp8 cache with 8 bytes per lane (one lane's 8-element operand fragment), i.e. 512 B per
+// wave instruction; a CU retires about one vector-memory wave instruction per ~38 cycles whatever its width, so the fp8
+// cache streamed at 3.6 TB/s against 6.4 TB/s for fp16 (1 KiB per instruction). Here every load is 16 bytes per lane:
+//  * K: the cache's x = 16 chunk (16 elements of one token) feeds TWO k-steps of S^T = K . Q^T - the k order of a
+//    contraction is free, so k-step 2 j + h takes elements 16 (4 j + g) + 8 h .. + 7 and the Q fragments are gathered
+//    to match;
+//  * V: a lane's 16 bytes of row d are 16 consecutive tokens = the operands of two P.V k-steps over a 64-token tile;
+//    the tokens are assigned to the rows of the four 16-token S sub-tiles (tau below) so that the existing two-swap
+//    re-shape of P (p_to_operand) delivers exactly the tokens each V half holds.
+// Conversion and scaling of every element is scalar_t(float(fp8) * kv_scale) as in the reference
+// (quant_utils.cuh:293-345): results equal paged_attention_kernel's up to the summation order of the tile.
+template <typename scalar_t, int KV, int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const AttnParams p) {
+  static_assert(KV != NMX_KV_AUTO && D <= 128 && D % 16 == 0, "fp8 cache, head size <= 128");
+  constexpr int C16 = D / 16;        // 16-element chunks per head vector
+  constexpr int KP = (C16 + 3) / 4;  // pairs of k-steps of the QK^T product
+  constexpr int NT = D / 16;         // 16-wide d tiles of the output
+  constexpr int TILE = 64;
+
+  const int kvh = blockIdx.x / p.q_tiles;
+  const int qt = blockIdx.x % p.q_tiles;
+  const int seq = blockIdx.y;
+  const int part = blockIdx.z;
+  const int seq_len = p.seq_lens[seq];
+  int tok_begin = 0, tok_end = seq_len;
+  if (p.partitioned) {
+    tok_begin = part * kPartitionSize;
+    if (tok_begin >= seq_len) return;
+    tok_end = min(seq_len, tok_begin + kPartitionSize);
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const int li = lane & 15;
+  const int q_row = qt * 16 + li;
+  const bool q_valid = q_row < p.q_per_kv;
+  const int head = kvh * p.q_per_kv + (q_valid ? q_row : 0);
+
+  // Q fragments: k-step 2 j + h <- Q[q][16 (4 j + g) + 8 h .. + 7]
+  u32x4 qf[KP][2];
+  {
+    const scalar_t* qp = reinterpret_cast<const scalar_t*>(p.q) + (int64_t)seq * p.q_stride + (int64_t)head * D;
+#pragma unroll
+    for (int j = 0; j < KP; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c16 = 4 * j + g;
+        u32x4 v = {0, 0, 0, 0};
+        if (q_valid && c16 < C16) v = *reinterpret_cast<const u32x4*>(qp + c16 * 16 + 8 * h);
+        // kv_scale is applied ONCE to the query (and once to the output) instead of to every cache element: the cache
+        // values then convert exactly, and K . (s q) = (s K) . q up to one scalar_t rounding of s q in place of one per
+        // s K element (the reference's order, quant_utils.cuh:293-345) - same error size, half the conversion VALU
+        union { u32x4 u; scalar_t e[8]; } qs;
+        qs.u = v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qs.e[e] = Scalar<scalar_t>::from_f32(Scalar<scalar_t>::to_f32(qs.e[e]) * p.kv_scale);
+        qf[j][h] = qs.u;
+      }
+  }
+  const float slope = (p.alibi_slopes != nullptr && q_valid) ? p.alibi_slopes[head] : 0.f;
+  int bs_block_offset = 0, q_bs_block_id = 0;
+  if (p.sparse) {
+    q_bs_block_id = (seq_len - 1) / p.bs_block_size;
+    if (p.bs_head_sliding_step >= 0) bs_block_offset = (p.tp_rank * p.num_heads + head) * p.bs_head_sliding_step + 1;
+    else bs_block_offset = (p.tp_rank * p.num_kv_heads + kvh) * (-p.bs_head_sliding_step) + 1;
+  }
+  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  const uint8_t* kc = reinterpret_cast<const uint8_t*>(p.k_cache) + (int64_t)kvh * p.kv_head_stride;
+  const uint8_t* vc = reinterpret_cast<const uint8_t*>(p.v_cache) + (int64_t)kvh * p.kv_head_stride;
+  const int BS = p.block_size;
+  const int bs_mask = BS - 1;
+  const int last_tok = seq_len - 1;
+
+  // row i of S sub-tile u is token t0 + tau(u, i): sub-tiles 0, 1 hold the first 8 tokens of the four 16-token groups,
+  // sub-tiles 2, 3 the second 8 - after p_to_operand(sub 0, sub 1) lane group g holds tokens 16 g .. 16 g + 7, after
+  // p_to_operand(sub 2, sub 3) tokens 16 g + 8 .. 16 g + 15: the two halves of its 16-byte V loads
+  auto tau = [](int u, int i) { return 16 * (2 * (u & 1) + (i >> 3)) + 8 * (u >> 1) + (i & 7); };
+
+  float m_run = -FLT_MAX;
+  float l_part = 0.f;
+  f32x4 o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_k = [&](int t0, u32x4 (&kr)[4][KP], int64_t& vphys) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tok = min(t0 + tau(u, li), last_tok);
+      const int64_t phys = bt[tok >> p.bs_shift];
+      const uint8_t* kb = kc + phys * p.kv_block_stride + (tok & bs_mask) * 16;
+#pragma unroll
+      for (int j = 0; j < KP; ++j) {
+        const int c16 = 4 * j + g;
+        u32x4 v = {0, 0, 0, 0};
+        if (c16 < C16) v = NMX_KV_LOAD(reinterpret_cast<const u32x4*>(kb + (int64_t)c16 * BS * 16));
+        kr[u][j] = v;
+      }
+    }
+    vphys = bt[min(t0 + 16 * g, last_tok & ~15) >> p.bs_shift];
+  };
+  auto load_v = [&](int t0, int64_t vphys, u32x4 (&vr)[NT]) {
+    const int tokc = min(t0 + 16 * g, last_tok & ~15);
+    const uint8_t* vb = vc + vphys * p.kv_block_stride + (tokc & bs_mask);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) vr[nt] = NMX_KV_LOAD(reinterpret_cast<const u32x4*>(vb + (int64_t)(16 * nt + li) * BS));
+  };
+
+  const int n_tiles = (tok_end - tok_begin + TILE - 1) / TILE;
+  u32x4 kr[4][KP], kr_n[4][KP];
+  int64_t vphys = 0, vphys_n = 0;
+  if (wave < n_tiles) load_k(tok_begin + wave * TILE, kr, vphys);
+  for (int tile = wave; tile < n_tiles; tile += NW) {
+    const int t0 = tok_begin + tile * TILE;
+    const bool more = tile + NW < n_tiles;
+    u32x4 vr[NT];
+    load_v(t0, vphys, vr);
+    if (more) load_k(t0 + NW * TILE, kr_n, vphys_n);
+
+    f32x4 s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KP; ++j) {
+        s[u] = mfma_16x16x32<scalar_t>(cvt8_fp8_exact<scalar_t, KV>(u32x2{kr[u][j][0], kr[u][j][1]}), qf[j][0], s[u]);
+        s[u] = mfma_16x16x32<scalar_t>(cvt8_fp8_exact<scalar_t, KV>(u32x2{kr[u][j][2], kr[u][j][3]}), qf[j][1], s[u]);
+      }
+    }
+
+    bool msk[4][4];
+    float m_tile = -FLT_MAX;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = t0 + tau(u, 4 * g + r);
+        float v = s[u][r] * p.scale;
+        v += (slope != 0.f) ? slope * (float)(tok - seq_len + 1) : 0.f;
+        bool masked = tok >= seq_len;
+        if (p.sparse) {
+          const int kb_id = ((tok >> p.bs_shift) << p.bs_shift) / p.bs_block_size;
+          const bool is_remote = ((kb_id + bs_block_offset) % p.bs_vert_stride) == 0;
+          const bool is_local = kb_id > q_bs_block_id - p.bs_local_blocks;
+          masked = masked || !(is_remote || is_local);
+        }
+        msk[u][r] = masked;
+        s[u][r] = v;
+        m_tile = masked ? m_tile : fmaxf(m_tile, v);
+      }
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+
+    float psum = 0.f;
+    u32x2 pk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e[r] = msk[u][r] ? 0.f : __expf(s[u][r] - m_new);
+        psum += e[r];
+      }
+      pk[u][0] = pack2<scalar_t>(e[0], e[1]);
+      pk[u][1] = pack2<scalar_t>(e[2], e[3]);
+    }
+    l_part = l_part * alpha + psum;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+    }
+
+    const u32x4 pb_a = p_to_operand(pk[0], pk[1]);
+    const u32x4 pb_b = p_to_operand(pk[2], pk[3]);
+    const bool tail = t0 + TILE > seq_len;
+    const int nva = max(0, min(8, seq_len - (t0 + 16 * g))), nvb = max(0, min(8, seq_len - (t0 + 16 * g + 8)));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      u32x4 va = cvt8_fp8_exact<scalar_t, KV>(u32x2{vr[nt][0], vr[nt][1]});
+      u32x4 vb = cvt8_fp8_exact<scalar_t, KV>(u32x2{vr[nt][2], vr[nt][3]});
+      if (tail) {  // zero V past the end of the sequence: those bytes may decode to NaNs (attention_kernels.cu:420-430)
+#pragma unroll
+        for (int dw = 0; dw < 4; ++dw) {
+          va[dw] &= (nva >= 2 * dw + 2) ? 0xffffffffu : ((nva == 2 * dw + 1) ? 0x0000ffffu : 0u);
+          vb[dw] &= (nvb >= 2 * dw + 2) ? 0xffffffffu : ((nvb == 2 * dw + 1) ? 0x0000ffffu : 0u);
+        }
+      }
+      o[nt] = mfma_16x16x32<scalar_t>(va, pb_a, o[nt]);
+      o[nt] = mfma_16x16x32<scalar_t>(vb, pb_b, o[nt]);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < KP; ++j) kr[u][j] = kr_n[u][j];
+      vphys = vphys_n;
+    }
+  }
+
+  // ---- combine the NW waves through LDS ----
+  l_part += __shfl_xor(l_part, 16, 64);
+  l_part += __shfl_xor(l_part, 32, 64);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds_m = reinterpret_cast<float*>(smem);          // [NW][16]
+  float* lds_l = lds_m + NW * 16;                          // [NW][16]
+  float* lds_o = lds_l + NW * 16;                          // [NW][16][D]
+  if (g == 0) {
+    lds_m[wave * 16 + li] = m_run;
+    lds_l[wave * 16 + li] = l_part;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    // lane (g, q) holds O[q][16 nt + 4 g + r]
+    *reinterpret_cast<f32x4*>(lds_o + ((int64_t)wave * 16 + li) * D + 16 * nt + 4 * g) = o[nt];
+  }
+  __syncthreads();
+
+  const int t = threadIdx.x;
+  const int cq = t & 15;            // query row within the tile
+  const int cq_row = qt * 16 + cq;
+  if (cq_row >= p.q_per_kv) return;
+  const int chead = kvh * p.q_per_kv + cq_row;
+  float M = -FLT_MAX;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) M = fmaxf(M, lds_m[w * 16 + cq]);
+  float f[NW];
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    f[w] = __expf(lds_m[w * 16 + cq] - M);
+    L += lds_l[w * 16 + cq] * f[w];
+  }
+  const float inv = __fdividef(1.f, L + 1e-6f) * p.kv_scale;  // V was accumulated unscaled
+  scalar_t* outp;
+  if (p.partitioned) {
+    const int64_t pidx = ((int64_t)seq * p.num_heads + chead) * p.max_num_partitions + part;
+    outp = reinterpret_cast<scalar_t*>(p.out) + pidx * D;
+    if ((t >> 4) == 0) {
+      p.max_logits[pidx] = M;
+      p.exp_sums[pidx] = L;
+    }
+  } else {
+    outp = reinterpret_cast<scalar_t*>(p.out) + ((int64_t)seq * p.num_heads + chead) * D;
+  }
+  // thread handles d = 4 * (t >> 4) + {0..3}, stepping by 4 * (NW * 4)
+  for (int d0 = 4 * (t >> 4); d0 < D; d0 += 16 * NW) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + ((int64_t)w * 16 + cq) * D + d0);
+      acc += v * f[w];
+    }
+    acc *= inv;
+    union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
+    *reinterpret_cast<u32x2*>(outp + d0) = r.u;
+  }
+}
+
+
 // v2 reduce: grid (num_heads, num_seqs), one wave. Follows attention_kernels.cu:567-669.
 template <typename scalar_t>
 __global__ void paged_attention_v2_reduce_kernel(scalar_t* __restrict__ out, const float* __restrict__ exp_sums,
@@ -586,8 +872,28 @@ int launch_attn_nw(const AttnParams& p, int num_seqs, int num_partitions, hipStr
   return NMX_OK;
 }
 
+template <typename scalar_t, int KV, int D, int NW>
+int launch_attn_fp8w(const AttnParams& p, int num_seqs, int num_partitions, hipStream_t stream) {
+  const size_t smem = (size_t)NW * 16 * (2 + D) * sizeof(float);
+  dim3 grid(p.num_kv_heads * p.q_tiles, num_seqs, num_partitions);
+  paged_attention_fp8w_kernel<scalar_t, KV, D, NW><<<grid, dim3(NW * 64), smem, stream>>>(p);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
 template <typename scalar_t, int KV, int D>
 int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream_t stream) {
+  if constexpr (KV != NMX_KV_AUTO && D <= 128) {
+    // fp8 cache in blocks of >= 16 tokens: 64-token tiles, 16-byte loads (NMX_ATTN_FP8W=0: the 8-byte path, for A/B)
+    const char* e = nmx_tune(NMX_TUNE_ATTN_FP8W);
+    if (p.block_size >= 16 && !(e != nullptr && atoi(e) == 0)) {
+      const long wgs = (long)p.num_kv_heads * p.q_tiles * num_seqs * num_partitions;
+      int nw = wgs <= 128 ? 8 : 4;
+      if (const char* n = nmx_tune(NMX_TUNE_ATTN_NW)) nw = atoi(n) == 8 ? 8 : 4;
+      if (nw == 8) return launch_attn_fp8w<scalar_t, KV, D, 8>(p, num_seqs, num_partitions, stream);
+      return launch_attn_fp8w<scalar_t, KV, D, 4>(p, num_seqs, num_partitions, stream);
+    }
+  }
   // Few workgroups (small batch: batch 1 x 8 kv heads x 2 partitions = 16): a CU streams its partition at its own
   // per-CU rate whatever the rest of the chip does, so give every workgroup 8 waves (2 tiles of 32 tokens each at a
   // 512-token partition, all K / V requests of the partition in flight at once) instead of 4.
