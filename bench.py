@@ -95,6 +95,8 @@ def parse():
                     "0 = independent replicas")
     ap.add_argument("--no-fuse", action="store_true", help="int4: run the plain op sequence (split-K reduce launches, separate "
                     "rotary / reshape_and_cache) instead of the fused consumers - bit-identical results, more launches")
+    ap.add_argument("--awq-op", action="store_true", help="AWQ configs: call the checkpoint-layout awq_gemm op instead of the "
+                    "load-time repack + zero-point Marlin kernel that AWQLinearMethod uses")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
@@ -138,8 +140,10 @@ def random_weight(variant, K, N, group, device, gen):
 class Llama3Decode:
     """Synthetic Llama-3-8B decode step driver (the *caller* of the hot path; stands in for vllm's LlamaForCausalLM)."""
 
-    def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16, variant="int4", all_reduce=None, all_gather=None):
+    def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16, variant="int4", all_reduce=None, all_gather=None,
+                 awq_marlin=True):
         self.ops, self.cfg, self.B, self.L, self.dev = ops, cfg, batch, ctx, device
+        self.awq_marlin = awq_marlin  # AWQ configs: weights repacked at load (the layer's path); False = the raw awq_gemm op
         self.all_reduce, self.all_gather = all_reduce, all_gather  # tensor-parallel collectives (None: TP = 1)
         self.fuse = False  # int4 only: deferred split-K reduction + rotary / cache fusion (set by main)
         self.n_layers = n_layers
@@ -157,6 +161,9 @@ class Llama3Decode:
                 lw[name] = random_weight(variant, K, N, cfg["group"], device, g)
                 if variant == "gptq-exllama":
                     ops.gptq_shuffle(lw[name][0], lw[name][3], 4)  # exllama state machine, first apply (gptq.py:207-219)
+                if variant in ("awq70b", "awq70b-tp8rank") and self.awq_marlin:
+                    # AWQLinearMethod.process_weights_after_loading: one-time re-layout for the Marlin-format kernels
+                    lw[name] = ops.awq_marlin_repack(lw[name][0], lw[name][1], lw[name][2])
             lw["ln1"] = torch.ones(H, dtype=torch.float16, device=device)
             lw["ln2"] = torch.ones(H, dtype=torch.float16, device=device)
             self.layers.append(lw)
@@ -214,7 +221,9 @@ class Llama3Decode:
             return ops.cutlass_scaled_mm(qx, w[0], sx, w[1], torch.float16)
         if self.variant == "gptq-exllama":  # GPTQLinearMethod.apply (gptq.py:198-231); weights shuffled once at load
             return ops.gptq_gemm(x, w[0], w[1], w[2], w[3], True, 4)
-        # AWQLinearMethod.apply (awq.py:166-172)
+        # AWQLinearMethod.apply (awq.py:166-172); after the load-time repack: the zero-point Marlin kernel
+        if self.awq_marlin:
+            return ops.awq_marlin_gemm(x, w[0], w[1], w[2], x.shape[0], N, K)
         return ops.awq_gemm(x, w[0], w[2], w[1], 8)
 
     def attention(self, q, layer):
@@ -529,7 +538,7 @@ def main():
         dist.all_reduce(warm)  # communicator set-up outside the capture
         torch.cuda.synchronize()
     model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev, variant=args.config, all_reduce=all_reduce,
-                         all_gather=all_gather)
+                         all_gather=all_gather, awq_marlin=not args.awq_op)
 
     model.fuse = args.config == "int4" and not args.no_fuse
     model.step()  # eager once: allocates GEMM scratch outside capture
@@ -597,8 +606,8 @@ def main():
                         "sparse24": ("marlin_gemm_kernel", "splitk_reduce_kernel"),
                         "fp8": ("scaled_mm_kernel", ),
                         "gptq-exllama": ("gptq_gemm_kernel", "splitk_reduce_kernel"),
-                        "awq70b": ("awq_gemm_kernel", "splitk_reduce_kernel"),
-                        "awq70b-tp8rank": ("awq_gemm_kernel", "splitk_reduce_kernel")}[args.config]
+                        "awq70b": ("marlin_gemm_kernel", "awq_gemm_kernel", "splitk_reduce_kernel"),
+                        "awq70b-tp8rank": ("marlin_gemm_kernel", "awq_gemm_kernel", "splitk_reduce_kernel")}[args.config]
         att = [v for k, v in kb.items() if k.startswith("paged_attention")][0]
         gem_ms = sum(v["ms"] for v in gem)
         classes = {

@@ -173,6 +173,18 @@ int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, const float*
                                int head_size, int block_size, int dtype, int kv_dtype, float kv_scale,
                                nmx_stream_t stream);
 
+/* AWQ checkpoints on the Marlin-format kernels (no reference counterpart in this snapshot; the reference repacks GPTQ ->
+ * Marlin at load the same way, gptq_marlin.py:330-420). One-time repack of qweight [size_k, size_n / 8] / qzeros
+ * [num_groups, size_n / 8] (AWQ nibble order) / scales [num_groups, size_n] fp16 into out_q [size_k / 16, size_n * 2],
+ * out_scales and out_zeros [num_groups, size_n] fp16 (zeros stored as -(1024 + z)), then
+ * c = a * ((q - z) * s) with the arithmetic of awq/dequantize.cuh:17-98. Supported when the group size is a multiple of
+ * 128 and size_n of 64 (nmx_awq_marlin_supported); otherwise use nmx_awq_gemm. fp16 only (as AWQ in the reference). */
+int nmx_awq_marlin_supported(int size_n, int size_k, int num_groups);
+int nmx_awq_marlin_repack(const int32_t* qweight, const int32_t* qzeros, const void* scales, int32_t* out_q,
+                          void* out_scales, void* out_zeros, int size_k, int size_n, int num_groups, nmx_stream_t stream);
+int nmx_awq_marlin_gemm(const void* a, const int32_t* q, const void* scales, const void* zeros, void* c, void* scratch,
+                        int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_groups, nmx_stream_t stream);
+
 /* marlin_gemm (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136): int4, fp16, groups of 128 or
  * channel-wise, weights Marlin-packed in the checkpoint. */
 int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,

@@ -692,6 +692,42 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, s
     return out
 
 
+def awq_marlin_supported(size_n: int, size_k: int, num_groups: int) -> bool:
+    return bool(_lib.lib().nmx_awq_marlin_supported(c_int(size_n), c_int(size_k), c_int(num_groups)))
+
+
+def awq_marlin_repack(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor):
+    """One-time re-layout of an AWQ checkpoint tensor triple for awq_marlin_gemm (extension; see include/nmx.h).
+    Returns (marlin_q [K / 16, 2 N] int32, marlin_scales [G, N], marlin_zeros [G, N]) fp16."""
+    _dev(qweight)
+    k, n = qweight.shape[0], qweight.shape[1] * 8
+    groups = scales.shape[0]
+    if scales.dtype != torch.float16 or scales.shape[1] != n or qzeros.shape != (groups, n // 8):
+        raise RuntimeError("awq_marlin_repack: scales [G, N] fp16 and qzeros [G, N / 8] expected")
+    out_q = torch.empty((k // 16, n * 2), dtype=torch.int32, device=qweight.device)
+    out_s = torch.empty((groups, n), dtype=torch.float16, device=qweight.device)
+    out_z = torch.empty((groups, n), dtype=torch.float16, device=qweight.device)
+    _lib.check(_lib.lib().nmx_awq_marlin_repack(_p(qweight.contiguous()), _p(qzeros.contiguous()), _p(scales.contiguous()),
+                                                _p(out_q), _p(out_s), _p(out_z), c_int(k), c_int(n), c_int(groups),
+                                                _stream(qweight)))
+    return out_q, out_s, out_z
+
+
+def awq_marlin_gemm(a: torch.Tensor, marlin_q: torch.Tensor, marlin_scales: torch.Tensor, marlin_zeros: torch.Tensor,
+                    size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    _dev(a)
+    if a.dtype != torch.float16 or a.dim() != 2 or a.shape[0] != size_m or a.shape[1] != size_k or not a.is_contiguous():
+        raise RuntimeError("awq_marlin_gemm: a must be a contiguous fp16 [size_m, size_k] tensor")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return c
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    _lib.check(_lib.lib().nmx_awq_marlin_gemm(_p(a), _p(marlin_q), _p(marlin_scales), _p(marlin_zeros), _p(c), _p(scratch),
+                                              c_i64(scratch.numel()), c_int(size_m), c_int(size_n), c_int(size_k),
+                                              c_int(marlin_scales.shape[0]), _stream(a)))
+    return c
+
+
 def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor, b_gptq_scales: torch.Tensor,
               b_g_idx: torch.Tensor, use_exllama: bool, bit: int) -> torch.Tensor:
     # csrc/quantization/gptq/q_gemm.cu:1823-1848

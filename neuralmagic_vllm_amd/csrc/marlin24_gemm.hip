@@ -31,7 +31,7 @@ extern "C" int nmx_gptq_marlin_24_gemm(const void* a, const int32_t* b_q_weight,
             NMX_ERR_INVALID_ARG, "gptq_marlin_24_gemm: operands must be 16-byte aligned");
   if (size_m == 0 || size_n == 0) return NMX_OK;
   GemmParams p;
-  p.a = a; p.b = b_q_weight; p.meta = b_meta; p.scales = b_scales; p.g_idx = nullptr; p.perm = nullptr; p.c = c;
+  p.a = a; p.b = b_q_weight; p.meta = b_meta; p.zeros = nullptr; p.scales = b_scales; p.g_idx = nullptr; p.perm = nullptr; p.c = c;
   p.partial = nullptr; p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.group_size = group_size;
   p.k_splits = 1; p.slow_act_order = 0; p.defer_reduce = 0;
   if (num_bits == 4) return launch_skinny<f16, W_INT4, true>(p, scratch, scratch_bytes, stream);

@@ -18,7 +18,7 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   NMX_CHECK(num_groups >= 1, NMX_ERR_INVALID_ARG, "b_scales must have at least one row");
   const bool has_act_order = g_idx != nullptr;
   GemmParams p;
-  p.a = a; p.b = b_q_weight; p.meta = nullptr; p.scales = b_scales; p.g_idx = g_idx; p.perm = perm; p.c = c; p.partial = nullptr;
+  p.a = a; p.b = b_q_weight; p.meta = nullptr; p.zeros = nullptr; p.scales = b_scales; p.g_idx = g_idx; p.perm = perm; p.c = c; p.partial = nullptr;
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.k_splits = 1; p.slow_act_order = 0;
   p.defer_reduce = defer_reduce;
   if (splits_out != nullptr) *splits_out = 1;

@@ -128,6 +128,20 @@ struct Dequant<f16, W_INT4> {
   }
 };
 
+// int4 with a per-(group, column) zero point (AWQ): zneg = (-(1024 + z), -(1024 + z)), zhi = (-(64 + z), -(64 + z)).
+// (1024 + q) - (1024 + z) and (1024 + 16 q) / 16 - (64 + z) are exact: the same two operations per pair as the symmetric form.
+__device__ __forceinline__ void dequant_zp_f16(uint32_t q, uint32_t s2, bool scaled, uint32_t zneg, uint32_t zhi, uint32_t& w01, uint32_t& w23) {
+  const f16x2 a = bits_h2(and_or(q, 0x000f000fu, 0x64006400u)) + bits_h2(zneg);
+  const f16x2 b = bits_h2(and_or(q, 0x00f000f0u, 0x64006400u)) * bits_h2(0x2c002c00u) + bits_h2(zhi);
+  if (scaled) {
+    w01 = h2_bits(a * bits_h2(s2));
+    w23 = h2_bits(b * bits_h2(s2));
+  } else {
+    w01 = h2_bits(a);
+    w23 = h2_bits(b);
+  }
+}
+
 template <>
 struct Dequant<f16, W_INT8> {
   // bytes b0 b1 b2 b3 = v0 v2 v1 v3 (k-rows 2m, 2m+8, 2m+1, 2m+9); zero point 128
@@ -211,6 +225,7 @@ struct GemmParams {
   const int32_t* b;        // Marlin-packed weight (2:4: compressed non-zeros, Marlin-24 permutation)
   const void* meta;        // 2:4 only: [K/32, 2N] int16 CUTLASS-reordered 2-bit indices
   const void* scales;      // [num_groups, N] Marlin-permuted
+  const void* zeros;       // ZP kernels only: [num_groups, N] fp16 -(1024 + z), permuted like the grouped scales
   const int32_t* g_idx;    // [K] or null
   const int32_t* perm;     // [K] or null
   void* c;                 // [M, N] scalar_t
@@ -249,9 +264,11 @@ struct GemmParams {
 // W8 = true: 8 waves per workgroup (twice the K slices for the same column groups): two waves per SIMD are then
 // resident BY CONSTRUCTION and fill each other's stalls, without doubling the cross-workgroup K splits (and their
 // fp32 partial traffic) that two co-resident 4-wave workgroups would need.
-template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP = false, bool W8 = false>
+// ZP = true (fp16, int4, MODE 1): per-(group, column) zero points from p.zeros (AWQ weights repacked into the Marlin layout).
+template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP = false, bool W8 = false, bool ZP = false>
 __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const GemmParams p) {
   static_assert(!SP || (__is_same(scalar_t, f16) && KIND != W_FP8), "2:4 path: fp16, int4 / int8 weights");
+  static_assert(!ZP || (__is_same(scalar_t, f16) && KIND == W_INT4 && MODE == 1 && !SP), "zero points: fp16, int4, 128-multiple groups");
   constexpr bool I4 = (KIND == W_INT4);
   constexpr bool GENERIC = (MODE == 2);
   constexpr int SUB = I4 ? 4 : 2;                     // 32-k steps per sub-chunk
@@ -312,6 +329,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   const int64_t scale_off = (int64_t)((col_ok ? n0 : 0) / 64) * 64 + 8 * c8 + 4 * hi;
 
   uint32_t s2[NTILE];
+  uint32_t zc[ZP ? NTILE : 1];  // zero points of the lane's four tile columns as packed fp16 pairs -(1024 + z)
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) s2[t] = 0;
   int cur_group = -1;
@@ -500,6 +518,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       u32x4 wf;
       if constexpr ((NMX_ABLATE & 2) != 0) {
         wf = u32x4{w0, w1, w0 ^ s2[t], w1};
+      } else if constexpr (ZP) {
+        const uint32_t zh = h2_bits(bits_h2(zc[t]) + bits_h2(0x63806380u));  // -(1024 + z) + 960 = -(64 + z), exact
+        dequant_zp_f16(w0, s2[t], GA == 0, zc[t], zh, d0, d1);
+        dequant_zp_f16(w1, s2[t], GA == 0, zc[t], zh, d2, d3);
+        wf = u32x4{d0, d1, d2, d3};
       } else if (!slow_act) {
         Dequant<scalar_t, KIND>::run(w0, s2[t], grouped && GA == 0, d0, d1);
         Dequant<scalar_t, KIND>::run(w1, s2[t], grouped && GA == 0, d2, d3);
@@ -601,7 +624,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     // pattern is the same in every iteration, prologue included.)
     constexpr int AD = 2;
     constexpr int NSC = (MODE == 1) ? (ACC_SCALE ? 4 : 1) : 0;  // scale loads per batch
-    constexpr int BATCH = PIECES + NSC;
+    constexpr int BATCH = PIECES + NSC + (ZP ? 1 : 0);
     constexpr int WI = X4 ? 1 : 2;                    // weight load instructions per k-step
     constexpr int WAIT_B = WI * (PF - 1) + 2 * BATCH;
     constexpr int WAIT_BATCH = AD * WI * SUB + (AD - 1) * BATCH;
@@ -609,6 +632,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     BStep ring[PF];
     ARegs areg[AD];
     u32x2 sraw[AD][4];
+    u32x2 zraw[AD];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       ring[i].q0 = bvec_t{};
@@ -621,6 +645,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       for (int i = 0; i < PIECES; ++i) areg[d].v[i] = u32x4{0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; ++i) sraw[d][i] = u32x2{0, 0};
+      zraw[d] = u32x2{0, 0};
     }
 
     // fast modes require K % (32 SUB) == 0, so every k-tile row of an in-range k-step exists; rows past the end of
@@ -630,6 +655,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     const i32x4 rs_a = make_rsrc(p.a, (uint32_t)((int64_t)M * K * sizeof(scalar_t)));
     const i32x4 rs_s = make_rsrc(p.scales, (uint32_t)((int64_t)p.num_groups * N * sizeof(scalar_t)));
     const i32x4 rs_m = make_rsrc(SP ? p.meta : p.b, SP ? (uint32_t)((int64_t)ktiles * N * 4) : 0u);
+    const i32x4 rs_z = make_rsrc(ZP ? p.zeros : p.scales, ZP ? (uint32_t)((int64_t)p.num_groups * N * sizeof(scalar_t)) : 0u);
+    const int z_voff = (int)(scale_off * sizeof(scalar_t));  // weight layout: positions 8 c8 + 4 hi + t
     const int b_voff = X4 ? (int)((bw - p.b - 2 * hi) * 4) + hi * row_bytes : (int)((bw - p.b) * 4);
     const int m_voff = (int)(meta_off * 2);
     auto issue_b = [&](int kstep, BStep& r) {
@@ -683,6 +710,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
 #pragma unroll
         for (int r = 0; r < NSC; ++r)
           buf_load_x2(sraw[SET][r], s_voff + 8 * r * (int)sizeof(scalar_t), rs_s, grp * N * (int)sizeof(scalar_t));
+        if constexpr (ZP) buf_load_x2(zraw[SET], z_voff, rs_z, grp * N * (int)sizeof(scalar_t));
       }
     };
     // make the landed batch usable: zero the out-of-range pieces, write the fragments, unpack the scales
@@ -696,6 +724,17 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
         for (int it = 0; it < PIECES; ++it) areg[SET].v[it] = u32x4{0, 0, 0, 0};
       }
       if constexpr ((NMX_ABLATE & 256) == 0) store_a(areg[SET], buf);
+      if constexpr (ZP) {
+        union { u32x2 v; f16 e[4]; } zr;
+        zr.v = zraw[SET];
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          union { f16 h[2]; uint32_t u; } pk;
+          pk.h[0] = zr.e[t];
+          pk.h[1] = zr.e[t];
+          zc[t] = pk.u;
+        }
+      }
       if constexpr (ACC_SCALE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -725,19 +764,20 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       constexpr int SET = decltype(set_c)::value;
       ARegs& ar = areg[SET];
       u32x2(&sr)[4] = sraw[SET];
+      u32x2& zr = zraw[SET];
       // binds every batch destination so that no use can be scheduled above the wait
       if constexpr (PIECES == 1)
-        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ar.v[0]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ar.v[0]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr)
                      : "n"(WAIT_BATCH) : "memory");
       else if constexpr (PIECES == 2)
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])
+        asm volatile("s_waitcnt vmcnt(%7)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr)
                      : "n"(WAIT_BATCH) : "memory");
       else if constexpr (PIECES == 4)
-        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(sr[0]),
-                     "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]) : "n"(WAIT_BATCH) : "memory");
+        asm volatile("s_waitcnt vmcnt(%9)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(sr[0]),
+                     "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr) : "n"(WAIT_BATCH) : "memory");
       else
-        asm volatile("s_waitcnt vmcnt(%12)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(ar.v[4]),
-                     "+v"(ar.v[5]), "+v"(ar.v[6]), "+v"(ar.v[7]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])
+        asm volatile("s_waitcnt vmcnt(%13)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(ar.v[4]),
+                     "+v"(ar.v[5]), "+v"(ar.v[6]), "+v"(ar.v[7]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr)
                      : "n"(WAIT_BATCH) : "memory");
     };
     using S0 = std::integral_constant<int, 0>;
@@ -1473,7 +1513,7 @@ GemmCfg pick_cfg(int M, int N, int K) {
   return c;
 }
 
-template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP, bool W8 = false>
+template <typename scalar_t, int KIND, int MT, int NG, int MODE, bool SP, bool W8 = false, bool ZP = false>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr int SUB = (KIND == W_INT4) ? 4 : 2;
   constexpr int KW = (W8 ? 8 : 4) / NG;
@@ -1482,7 +1522,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
   const size_t smem = std::max(stage, red);
   // x = (column tiles rounded up to the 8 XCDs) x row blocks, see the kernel's blockIdx decoding
   dim3 grid(ceil_div(ceil_div(p.N, 64 * NG), 8) * 8 * ceil_div(p.M, 16 * MT), p.k_splits, 1);
-  auto kern = marlin_gemm_kernel<scalar_t, KIND, MT, NG, MODE, SP, W8>;
+  auto kern = marlin_gemm_kernel<scalar_t, KIND, MT, NG, MODE, SP, W8, ZP>;
   if (smem > 64 * 1024)
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   kern<<<grid, W8 ? 512 : 256, smem, stream>>>(p);
@@ -1490,17 +1530,17 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
   return NMX_OK;
 }
 
-template <typename scalar_t, int KIND, int MODE, bool SP>
+template <typename scalar_t, int KIND, int MODE, bool SP, bool ZP = false>
 int launch_mode(const GemmParams& p, const GemmCfg& cfg, hipStream_t stream) {
-  if (cfg.w8 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 4, 2, MODE, SP, true>(p, stream);
-  if (cfg.w8) return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP, true>(p, stream);
-  if (cfg.mt == 1 && cfg.ng == 1) return launch_cfg<scalar_t, KIND, 1, 1, MODE, SP>(p, stream);
-  if (cfg.mt == 1 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 1, 2, MODE, SP>(p, stream);
-  if (cfg.mt == 1) return launch_cfg<scalar_t, KIND, 1, 4, MODE, SP>(p, stream);
-  if (cfg.mt == 2 && cfg.ng == 4) return launch_cfg<scalar_t, KIND, 2, 4, MODE, SP>(p, stream);
-  if (cfg.mt == 2) return launch_cfg<scalar_t, KIND, 2, 2, MODE, SP>(p, stream);
-  if (cfg.mt == 4 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 4, 2, MODE, SP>(p, stream);
-  return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP>(p, stream);
+  if (cfg.w8 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 4, 2, MODE, SP, true, ZP>(p, stream);
+  if (cfg.w8) return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP, true, ZP>(p, stream);
+  if (cfg.mt == 1 && cfg.ng == 1) return launch_cfg<scalar_t, KIND, 1, 1, MODE, SP, false, ZP>(p, stream);
+  if (cfg.mt == 1 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 1, 2, MODE, SP, false, ZP>(p, stream);
+  if (cfg.mt == 1) return launch_cfg<scalar_t, KIND, 1, 4, MODE, SP, false, ZP>(p, stream);
+  if (cfg.mt == 2 && cfg.ng == 4) return launch_cfg<scalar_t, KIND, 2, 4, MODE, SP, false, ZP>(p, stream);
+  if (cfg.mt == 2) return launch_cfg<scalar_t, KIND, 2, 2, MODE, SP, false, ZP>(p, stream);
+  if (cfg.mt == 4 && cfg.ng == 2) return launch_cfg<scalar_t, KIND, 4, 2, MODE, SP, false, ZP>(p, stream);
+  return launch_cfg<scalar_t, KIND, 4, 4, MODE, SP, false, ZP>(p, stream);
 }
 
 // K splits of the large-M kernel: enough workgroups for the 256 CUs, stages of 64 k

@@ -578,7 +578,7 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
 
 int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream) {
   GemmParams p;
-  p.a = call.a; p.b = call.b; p.meta = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
+  p.a = call.a; p.b = call.b; p.meta = nullptr; p.zeros = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
   p.M = call.M; p.N = call.N; p.K = call.K; p.num_groups = call.num_groups; p.group_size = call.group_size;
   p.slow_act_order = 0;
   p.defer_reduce = call.defer_reduce;

@@ -69,11 +69,29 @@ class AWQLinearMethod(LinearMethodBase):
             layer.register_parameter(name, prm)
             set_weight_attrs(prm, extra_weight_attrs)
 
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        """MI355X-specific: re-lay the checkpoint tensors out for the Marlin-format kernels once (the per-call 8 x 8 nibble
+        transposition of awq_gemm is what keeps that op at < 1 TB/s); the reference does the same kind of load-time
+        repack for GPTQ -> Marlin (gptq_marlin.py:330-420). Falls back to awq_gemm where the shape does not allow it
+        (group size not a multiple of 128, CPU tensors)."""
+        qw = layer.qweight
+        if not qw.is_cuda or getattr(layer, "marlin_q", None) is not None:
+            return
+        k, n = qw.shape[0], qw.shape[1] * self.quant_config.pack_factor
+        if not ops.awq_marlin_supported(n, k, layer.scales.shape[0]) or layer.scales.dtype != torch.float16:
+            return
+        layer.marlin_q, layer.marlin_s, layer.marlin_z = ops.awq_marlin_repack(qw.data, layer.qzeros.data, layer.scales.data)
+        layer.marlin_shape = (k, n)
+
     def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         pack_factor = self.quant_config.pack_factor
         out_shape = x.shape[:-1] + (layer.qweight.shape[-1] * pack_factor, )
         reshaped_x = x.reshape(-1, x.shape[-1])
-        if x.shape[:-1].numel() >= 256:  # awq.py:166-170: large batches dequantise once and use a dense GEMM
+        if getattr(layer, "marlin_q", None) is not None and reshaped_x.dtype == torch.float16:
+            k, n = layer.marlin_shape
+            out = ops.awq_marlin_gemm(reshaped_x.contiguous(), layer.marlin_q, layer.marlin_s, layer.marlin_z,
+                                      reshaped_x.shape[0], n, k)
+        elif x.shape[:-1].numel() >= 256:  # awq.py:166-170: large batches dequantise once and use a dense GEMM
             out = torch.matmul(reshaped_x, ops.awq_dequantize(layer.qweight, layer.scales, layer.qzeros, 0, 0, 0))
         else:
             out = ops.awq_gemm(reshaped_x, layer.qweight, layer.scales, layer.qzeros, pack_factor)

@@ -227,3 +227,45 @@ def test_cross_format_agreement(ops, m, bits, group):
         assert compute_max_diff(c_awq, ref) < TOL and compute_max_diff(c_awq, c_marlin) < TOL
         deq = ops.awq_dequantize(packing.awq_pack(q_w).to(DEV), s.to(DEV), packing.awq_pack(zeros).to(DEV), 0, 0, 0).cpu()
         assert torch.equal(deq.view(torch.int16), w_ref.view(torch.int16))  # the reference quantizer's own w_ref, bit for bit
+
+
+@pytest.mark.parametrize("m", [1, 16, 33, 64, 100, 256, 300])
+@pytest.mark.parametrize("k,n", [(1024, 1280), (8192, 1280), (1024, 8192), (3584, 8192), (512, 256)])
+def test_awq_marlin_path(ops, m, k, n):
+    """AWQ checkpoint -> awq_marlin_repack -> awq_marlin_gemm (what AWQLinearMethod runs after loading): same bar as
+    awq_gemm against a @ w_ref, and agreement with the checkpoint-layout op on the same weights. The shapes are the
+    Llama-3-70B / TP=8 per-rank ones (BASELINE configs[4])."""
+    if (k, n) in ((8192, 1280), (3584, 8192)) and m not in (1, 64, 256):
+        pytest.skip("large shapes covered at three batch sizes")
+    seed_all(m)
+    w = torch.randn(k, n)
+    a = torch.randn(m, k, dtype=torch.float16)
+    w_ref, qweight, qzeros, scales = packing.awq_quantize(w, 128)
+    assert ops.awq_marlin_supported(n, k, k // 128)
+    mq, ms, mz = ops.awq_marlin_repack(qweight.to(DEV), qzeros.to(DEV), scales.to(DEV))
+    out = ops.awq_marlin_gemm(a.to(DEV), mq, ms, mz, m, n, k).float().cpu()
+    assert compute_max_diff(out, a.float() @ w_ref.float()) < TOL
+    base = ops.awq_gemm(a.to(DEV), qweight.to(DEV), scales.to(DEV), qzeros.to(DEV), 8).float().cpu()
+    assert compute_max_diff(out, base) < TOL
+    # the repacked codes are the Marlin layout of the same integer matrix (reference packer: marlin_weights)
+    codes = torch.from_numpy(np.stack([(qweight.numpy().astype(np.uint32) >> (4 * packing._AWQ_ORDER[j])) & 0xf for j in range(8)],
+                                      axis=2).reshape(k, n).astype(np.int32))
+    assert torch.equal(mq.cpu(), packing.marlin_weights(codes, k, n, 4))
+
+
+def test_awq_layer_uses_marlin_path(ops):
+    from neuralmagic_vllm_amd.layers.linear import ColumnParallelLinear
+    from neuralmagic_vllm_amd.layers.quantization.awq import AWQConfig
+    seed_all(5)
+    K, N = 1024, 512
+    w_ref, qweight, qzeros, scales = packing.awq_quantize(torch.randn(K, N), 128)
+    layer = ColumnParallelLinear(K, N, AWQConfig(4, 128, True))
+    for name, t in (("qweight", qweight), ("qzeros", qzeros), ("scales", scales)):
+        prm = getattr(layer, name)
+        prm.weight_loader(prm, t)
+        prm.data = prm.data.to(DEV)
+    layer.quant_method.process_weights_after_loading(layer)
+    assert layer.marlin_q is not None
+    x = torch.randn(40, K, dtype=torch.float16)
+    y = layer(x.to(DEV))
+    assert compute_max_diff(y.cpu(), x.float() @ w_ref.float()) < TOL
