@@ -291,6 +291,24 @@ int nmx_activation(void* out, const void* input, int num_tokens, int d, int act,
 int nmx_get_max_shared_memory_per_block_device_attribute(int device, int* value);
 int nmx_get_device_attribute(int attribute, int device, int* value);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * One-shot all-reduce over the xGMI mesh for small messages. Replaces the `_C_custom_ar` ops of the reference
+ * (csrc/custom_all_reduce.cu: meta_size, init_custom_ar, register_buffer, should_custom_ar, all_reduce_reg, dispose;
+ * kernel csrc/custom_all_reduce.cuh:179-255, thresholds :442-450). The host side exchanges IPC handles
+ * (nmx_ipc_*: hipIpcGetMemHandle / hipIpcOpenMemHandle, 64-byte handles) and hands over every rank's pointers as
+ * mapped in the calling process. Only the one-stage schedule exists: nmx_custom_ar_should() is true for the sizes it
+ * serves (world 2: <= max_size; full mesh: < 512 KiB at <= 4 ranks, < 256 KiB at 6 / 8), everything else stays on RCCL.
+ * ---------------------------------------------------------------------------------------------------------- */
+int64_t nmx_custom_ar_meta_size(void);
+int nmx_custom_ar_init(void* const* signal_ptrs, int rank, int world_size, void** fa_out);
+int nmx_custom_ar_register_buffer(void* fa, void* const* peer_ptrs);
+int nmx_custom_ar_should(int64_t bytes, int64_t max_size, int world_size, int full_xgmi);
+int nmx_custom_ar_all_reduce(void* fa, const void* inp, void* out, int64_t numel, int dtype, nmx_stream_t stream);
+int nmx_custom_ar_dispose(void* fa);
+int nmx_ipc_get_mem_handle(const void* ptr, void* handle64);
+int nmx_ipc_open_mem_handle(const void* handle64, void** ptr);
+int nmx_ipc_close_mem_handle(void* ptr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,11 +23,22 @@ class GroupCoordinator:
         self.local_rank = local_rank
         self.device_group = dist.new_group(self.ranks, backend=backend)
         self.backend = backend
+        # small decode messages: the one-shot xGMI all-reduce, attached to a CPU (gloo) group for the IPC-handle exchange
+        # like the reference (parallel_state.py:166-179). Off unless NMX_CUSTOM_AR=1 (custom_all_reduce.py).
+        self.ca_comm = None
+        if backend == "nccl" and self.world_size > 1 and os.environ.get("NMX_CUSTOM_AR", "0") == "1":
+            from neuralmagic_vllm_amd.distributed.custom_all_reduce import CustomAllreduce
+            self.cpu_group = dist.new_group(self.ranks, backend="gloo")
+            self.ca_comm = CustomAllreduce(self.cpu_group, torch.device("cuda", local_rank))
 
     def all_reduce(self, input_: torch.Tensor) -> torch.Tensor:
         """In-place SUM over the group (parallel_state.py:273-293). Bypassed for world size 1."""
         if self.world_size == 1:
             return input_
+        if self.ca_comm is not None:
+            out = self.ca_comm.custom_all_reduce(input_)  # None: message not served by the one-shot kernel
+            if out is not None:
+                return out
         dist.all_reduce(input_, group=self.device_group)
         return input_
 
