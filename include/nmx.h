@@ -292,6 +292,19 @@ int nmx_get_max_shared_memory_per_block_device_attribute(int device, int* value)
 int nmx_get_device_attribute(int attribute, int device, int* value);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Mixture-of-experts routing. topk_softmax replaces `_moe_C.topk_softmax` (csrc/moe/topk_softmax_kernels.cu:476-507):
+ * softmax over gating_output [num_tokens, num_experts] fp32, the topk largest (ties: lowest expert id) into
+ * topk_weights / topk_ids [num_tokens, topk]; token_expert_indices[t][j] = j * num_tokens + t.
+ * moe_align_block_size replaces csrc/moe_align_block_size_kernels.cu:108-125: the numel flat (token, k) pairs sorted by
+ * expert, each expert's run padded to a multiple of block_size with the value numel; expert_ids[b] = expert of block b;
+ * *num_tokens_post_pad = padded length. sorted_token_ids must hold max_sorted >= numel + num_experts * (block_size - 1).
+ * ---------------------------------------------------------------------------------------------------------- */
+int nmx_topk_softmax(float* topk_weights, int32_t* topk_ids, int32_t* token_expert_indices, const float* gating_output,
+                     int num_tokens, int num_experts, int topk, nmx_stream_t stream);
+int nmx_moe_align_block_size(const int32_t* topk_ids, int num_experts, int block_size, int numel, int32_t* sorted_token_ids,
+                             int max_sorted, int32_t* expert_ids, int32_t* num_tokens_post_pad, nmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * One-shot all-reduce over the xGMI mesh for small messages. Replaces the `_C_custom_ar` ops of the reference
  * (csrc/custom_all_reduce.cu: meta_size, init_custom_ar, register_buffer, should_custom_ar, all_reduce_reg, dispose;
  * kernel csrc/custom_all_reduce.cuh:179-255, thresholds :442-450). The host side exchanges IPC handles

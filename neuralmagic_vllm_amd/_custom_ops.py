@@ -877,6 +877,30 @@ def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
 
 
 # ---------------------------------------------------------------------------------------------------------
+# mixture-of-experts routing (vllm/_custom_ops.py:354-367)
+# ---------------------------------------------------------------------------------------------------------
+def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, block_size: int, sorted_token_ids: torch.Tensor,
+                         experts_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor) -> None:
+    _dev(topk_ids)
+    if topk_ids.dtype != torch.int32 or not topk_ids.is_contiguous():
+        raise RuntimeError("moe_align_block_size: topk_ids must be a contiguous int32 tensor")
+    _lib.check(_lib.lib().nmx_moe_align_block_size(_p(topk_ids), c_int(num_experts), c_int(block_size), c_int(topk_ids.numel()),
+                                                   _p(sorted_token_ids), c_int(sorted_token_ids.numel()), _p(experts_ids),
+                                                   _p(num_tokens_post_pad), _stream(topk_ids)))
+
+
+def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, token_expert_indicies: torch.Tensor,
+                 gating_output: torch.Tensor) -> None:
+    _dev(gating_output)
+    if gating_output.dtype != torch.float32 or not gating_output.is_contiguous() or gating_output.dim() != 2:
+        raise RuntimeError("topk_softmax: gating_output must be a contiguous float32 [num_tokens, num_experts] tensor")
+    t, e = gating_output.shape
+    k = topk_ids.shape[-1]
+    _lib.check(_lib.lib().nmx_topk_softmax(_p(topk_weights), _p(topk_ids), _p(token_expert_indicies), _p(gating_output),
+                                           c_int(t), c_int(e), c_int(k), _stream(gating_output)))
+
+
+# ---------------------------------------------------------------------------------------------------------
 # device utilities (vllm/_custom_ops.py:415-422)
 # ---------------------------------------------------------------------------------------------------------
 def get_device_attribute(attribute: int, device: int) -> int:

@@ -1,0 +1,94 @@
+"""Mixture-of-experts forward on the MI355X ops — the part of vllm/model_executor/layers/fused_moe/fused_moe.py that the
+fp8 MoE method calls (fused_topk :335-368, fused_experts :402-511, fused_moe :514-585). The reference runs ONE Triton
+grouped-GEMM kernel over tokens sorted by expert; here routing is native HIP (topk_softmax, moe_align_block_size) and
+each expert's two GEMMs run on the fp8 MFMA scaled_mm kernel (`cutlass_scaled_mm`) over its slice of the sorted rows.
+First version: correct and graph-free (the per-expert row counts are read on the host once per call); a grouped kernel
+over the sorted list is the known next step. Arithmetic follows the reference: one per-tensor activation scale for the
+whole batch (static, or dynamic = max over all tokens), per-expert weight scales, fp32 accumulation, routing weights
+applied to the expert outputs before the sum over k."""
+from typing import Optional, Tuple
+
+import torch
+
+from neuralmagic_vllm_amd import _custom_ops as ops
+
+
+def fused_topk(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: int, renormalize: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    assert hidden_states.shape[0] == gating_output.shape[0], "Number of tokens mismatch"
+    m = hidden_states.shape[0]
+    topk_weights = torch.empty(m, topk, dtype=torch.float32, device=hidden_states.device)
+    topk_ids = torch.empty(m, topk, dtype=torch.int32, device=hidden_states.device)
+    token_expert_indicies = torch.empty(m, topk, dtype=torch.int32, device=hidden_states.device)
+    ops.topk_softmax(topk_weights, topk_ids, token_expert_indicies, gating_output.float().contiguous())
+    if renormalize:
+        topk_weights = topk_weights / topk_weights.sum(dim=-1, keepdim=True)
+    return topk_weights, topk_ids
+
+
+def _expert_gemm(x: torch.Tensor, w: torch.Tensor, use_fp8: bool, a_scale: Optional[torch.Tensor], w_scale: Optional[torch.Tensor],
+                 out_dtype: torch.dtype) -> torch.Tensor:
+    """x [rows, K] (fp8 when use_fp8) @ w[N, K]^T."""
+    if use_fp8:
+        return ops.cutlass_scaled_mm(x, w.t(), a_scale, w_scale, out_dtype)
+    return torch.matmul(x, w.t())
+
+
+def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
+                  topk_ids: torch.Tensor, inplace: bool = False, use_fp8: bool = False, w1_scale: Optional[torch.Tensor] = None,
+                  w2_scale: Optional[torch.Tensor] = None, a1_scale: Optional[torch.Tensor] = None,
+                  a2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert hidden_states.shape[1] == w1.shape[2], "Hidden size mismatch"
+    assert topk_weights.shape == topk_ids.shape, "topk shape mismatch"
+    assert hidden_states.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
+    assert hidden_states.dtype in (torch.float32, torch.float16, torch.bfloat16)
+    m, k = hidden_states.shape
+    e, n2, _ = w1.shape
+    topk = topk_ids.shape[1]
+    dev, dt = hidden_states.device, hidden_states.dtype
+    # tokens sorted by expert (block size 1: no padding needed for per-expert slices)
+    numel = m * topk
+    sorted_ids = torch.empty(numel, dtype=torch.int32, device=dev)
+    expert_of_block = torch.empty(numel, dtype=torch.int32, device=dev)
+    post_pad = torch.empty(1, dtype=torch.int32, device=dev)
+    ops.moe_align_block_size(topk_ids.contiguous(), e, 1, sorted_ids, expert_of_block, post_pad)
+    counts = torch.bincount(expert_of_block.long(), minlength=e).tolist()  # rows per expert (one host read per call)
+    src_tok = (sorted_ids // topk).long()                                    # token of every sorted row
+    a = hidden_states.index_select(0, src_tok)                               # [numel, K] rows grouped by expert
+    if use_fp8:
+        a, a1 = ops.scaled_fp8_quant(a, a1_scale)                            # one scale for the whole batch (fused_moe.py:467-472)
+    inter = torch.empty(numel, n2 // 2, dtype=dt, device=dev)
+    gate_up = torch.empty(numel, n2, dtype=dt, device=dev)
+    row = 0
+    for ex, cnt in enumerate(counts):
+        if cnt:
+            gate_up[row:row + cnt] = _expert_gemm(a[row:row + cnt], w1[ex], use_fp8, a1 if use_fp8 else None,
+                                                  w1_scale[ex:ex + 1] if use_fp8 else None, dt)
+        row += cnt
+    ops.silu_and_mul(inter, gate_up)
+    if use_fp8:
+        inter, a2 = ops.scaled_fp8_quant(inter, a2_scale)
+    out_rows = torch.empty(numel, w2.shape[1], dtype=dt, device=dev)
+    row = 0
+    for ex, cnt in enumerate(counts):
+        if cnt:
+            out_rows[row:row + cnt] = _expert_gemm(inter[row:row + cnt], w2[ex], use_fp8, a2 if use_fp8 else None,
+                                                   w2_scale[ex:ex + 1] if use_fp8 else None, dt)
+        row += cnt
+    # routing weight per sorted row, then the sum over k per token (fused_moe.py: mul_routed_weight + moe_sum)
+    wts = topk_weights.reshape(-1).index_select(0, sorted_ids.long()).to(torch.float32)
+    out = hidden_states if inplace else torch.empty_like(hidden_states)
+    acc = torch.zeros(m, w2.shape[1], dtype=torch.float32, device=dev)
+    acc.index_add_(0, src_tok, out_rows.float() * wts[:, None])
+    out.copy_(acc.to(dt))
+    return out
+
+
+def fused_moe(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, gating_output: torch.Tensor, topk: int,
+              renormalize: bool, inplace: bool = False, use_fp8: bool = False, w1_scale: Optional[torch.Tensor] = None,
+              w2_scale: Optional[torch.Tensor] = None, a1_scale: Optional[torch.Tensor] = None,
+              a2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fused_moe.py:514-585: w1 [E, 2 N, K] (gate | up), w2 [E, K, N]; returns [M, K]."""
+    assert gating_output.shape[1] == w1.shape[0], "Number of experts mismatch"
+    topk_weights, topk_ids = fused_topk(hidden_states, gating_output, topk, renormalize)
+    return fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace=inplace, use_fp8=use_fp8, w1_scale=w1_scale,
+                         w2_scale=w2_scale, a1_scale=a1_scale, a2_scale=a2_scale)

@@ -110,6 +110,99 @@ class Fp8LinearMethod(LinearMethodBase):
         return out.reshape(x.shape[:-1] + (out.shape[-1], ))
 
 
+class Fp8MoEMethod(QuantizeMethodBase):
+    """MoE method for FP8 — mirror of fp8.py:382-560 (Fp8MoEMethod): fp8 or fp16/bf16 checkpoints, per-expert weight scales
+    (one for the merged w13 after loading), one static or dynamic activation scale. `apply` runs fused_moe on the
+    MI355X ops (layers/fused_moe.py)."""
+
+    def __init__(self, quant_config: Fp8Config):
+        self.quant_config = quant_config
+
+    def create_weights(self, layer: Module, num_experts: int, hidden_size: int, intermediate_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        layer.process_after_load = True
+        layer.num_experts = num_experts
+        layer.intermediate_size_per_partition = intermediate_size
+        if self.quant_config.is_checkpoint_fp8_serialized:
+            params_dtype = torch.float8_e4m3fn
+        w13_weight = Parameter(torch.empty(num_experts, 2 * intermediate_size, hidden_size, dtype=params_dtype), requires_grad=False)
+        layer.register_parameter("w13_weight", w13_weight)
+        set_weight_attrs(w13_weight, extra_weight_attrs)
+        w2_weight = Parameter(torch.empty(num_experts, hidden_size, intermediate_size, dtype=params_dtype), requires_grad=False)
+        layer.register_parameter("w2_weight", w2_weight)
+        set_weight_attrs(w2_weight, extra_weight_attrs)
+        # two scales for w1 and w3; combined into one after loading (fp8.py:424-441)
+        w13_scale = Parameter(torch.ones(num_experts, 2, dtype=torch.float32), requires_grad=False)
+        layer.register_parameter("w13_scale", w13_scale)
+        w2_scale = Parameter(torch.ones(num_experts, dtype=torch.float32), requires_grad=False)
+        layer.register_parameter("w2_scale", w2_scale)
+        if self.quant_config.is_checkpoint_fp8_serialized:
+            set_weight_attrs(w13_scale, extra_weight_attrs)
+            set_weight_attrs(w2_scale, extra_weight_attrs)
+        if self.quant_config.activation_scheme == "static":
+            if not self.quant_config.is_checkpoint_fp8_serialized:
+                raise ValueError("Found static activation scheme for checkpoint that was not serialized fp8.")
+            a13_scale = Parameter(torch.ones(num_experts, dtype=torch.float32), requires_grad=False)
+            layer.register_parameter("a13_scale", a13_scale)
+            set_weight_attrs(a13_scale, extra_weight_attrs)
+            a2_scale = Parameter(torch.ones(num_experts, dtype=torch.float32), requires_grad=False)
+            layer.register_parameter("a2_scale", a2_scale)
+            set_weight_attrs(a2_scale, extra_weight_attrs)
+        else:
+            layer.a13_scale = None
+            layer.a2_scale = None
+
+    def process_weights_after_loading(self, layer: Module) -> None:
+        if not getattr(layer, "process_after_load", False):
+            return
+        if not self.quant_config.is_checkpoint_fp8_serialized:
+            # fp16 / bf16 checkpoint: quantise every expert in place, one scale for the merged w13 (fp8.py:470-494)
+            w13 = torch.empty_like(layer.w13_weight.data, dtype=torch.float8_e4m3fn)
+            w2 = torch.empty_like(layer.w2_weight.data, dtype=torch.float8_e4m3fn)
+            w13_scale = torch.ones(layer.num_experts, dtype=torch.float32, device=w13.device)
+            w2_scale = torch.ones(layer.num_experts, dtype=torch.float32, device=w13.device)
+            for ex in range(layer.num_experts):
+                w13[ex], s13 = ops.scaled_fp8_quant(layer.w13_weight.data[ex])
+                w2[ex], s2 = ops.scaled_fp8_quant(layer.w2_weight.data[ex])
+                w13_scale[ex], w2_scale[ex] = s13[0], s2[0]
+            layer.w13_weight = Parameter(w13, requires_grad=False)
+            layer.w2_weight = Parameter(w2, requires_grad=False)
+            layer.w13_scale = Parameter(w13_scale, requires_grad=False)
+            layer.w2_scale = Parameter(w2_scale, requires_grad=False)
+            return
+        # fp8 checkpoint: one activation scale (max over the experts) and one w13 scale per expert (fp8.py:499-540)
+        if self.quant_config.activation_scheme == "static":
+            if layer.a13_scale is None or layer.a2_scale is None:
+                raise ValueError("QuantConfig has static quantization, but found activation scales are None.")
+            layer.a13_scale = Parameter(layer.a13_scale.max().reshape(1), requires_grad=False)
+            layer.a2_scale = Parameter(layer.a2_scale.max().reshape(1), requires_grad=False)
+        shard = layer.intermediate_size_per_partition
+        max_w13 = layer.w13_scale.max(dim=1).values
+        for ex in range(layer.num_experts):
+            for sid in range(2):
+                dq = per_tensor_dequantize(layer.w13_weight[ex][sid * shard:(sid + 1) * shard, :], layer.w13_scale[ex][sid])
+                layer.w13_weight[ex][sid * shard:(sid + 1) * shard, :] = per_tensor_quantize(dq, max_w13[ex])
+        layer.w13_scale = Parameter(max_w13, requires_grad=False)
+
+    def apply(self, layer: Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int, renormalize: bool = True) -> torch.Tensor:
+        from neuralmagic_vllm_amd.layers.fused_moe import fused_moe
+        return fused_moe(x, layer.w13_weight, layer.w2_weight, router_logits, top_k, renormalize=renormalize, inplace=True,
+                         use_fp8=True, w1_scale=layer.w13_scale, w2_scale=layer.w2_scale, a1_scale=layer.a13_scale,
+                         a2_scale=layer.a2_scale)
+
+
+def per_tensor_quantize(tensor: torch.Tensor, inv_scale) -> torch.Tensor:
+    """fp8.py:612-617"""
+    finfo = torch.finfo(torch.float8_e4m3fn)
+    qweight = (tensor / inv_scale).clamp(min=finfo.min, max=finfo.max)
+    return qweight.to(torch.float8_e4m3fn)
+
+
+def per_tensor_dequantize(tensor: torch.Tensor, inv_scale) -> torch.Tensor:
+    """fp8.py:620-624"""
+    return tensor.to(torch.float16) * inv_scale
+
+
 class Fp8KVCacheMethod(QuantizeMethodBase):
     """fp8 KV-cache scaling factor loaded from the checkpoint or a JSON file (fp8.py:563-598); reaches the kernels as the
     scalar `kv_scale` of reshape_and_cache / paged_attention."""
