@@ -72,12 +72,14 @@ def test_contexted_kv_attention(ops, heads, head_size, sliding_window, dtype):
     torch.testing.assert_close(out.float(), ref, **tol)
 
 
-@pytest.mark.parametrize("gq", ["1", "2"])
+@pytest.mark.parametrize("gq", ["1", "2", "11", "12", "14"])
 @pytest.mark.parametrize("heads", [(8, 2), (8, 1), (6, 3)])
-@pytest.mark.parametrize("head_size", [128, 80])
+@pytest.mark.parametrize("head_size", [128, 80, 64])
 def test_two_heads_per_wave_shape(ops, tune, gq, heads, head_size):
-    """Both launch shapes of the kernel (one / two query heads of a kv head per wave; the second is the default only from
-    256 new tokens) on the same ragged case, with alibi, plus a long prompt that takes the default route."""
+    """Every launch shape of the kernel - per-wave K / V loads with one / two query heads of a kv head per wave ("1", "2")
+    and the workgroup-shared LDS tiles with one / two / four heads per wave ("11", "12", "14"; head sizes that are a
+    multiple of 64, other sizes fall back) - on the same ragged case, with alibi, plus a long prompt that takes the
+    default route."""
     seed_all(3)
     tune(NMX_PREFILL_GQ=gq)
     c = make_case(5, heads[0], heads[1], head_size, 16, torch.float16, max_q=200, max_ctx=150)

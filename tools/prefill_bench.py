@@ -6,8 +6,14 @@ import torch
 from neuralmagic_vllm_amd.attention.ops.prefix_prefill import context_attention_fwd
 
 dev = "cuda:0"
+from neuralmagic_vllm_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1] != "0":
+    _lib.set_tuning("NMX_PREFILL_GQ", sys.argv[1])
 H, Hkv, D, BS = 32, 8, 128, 16
-for batch, n_new, ctx in ((8, 1024, 0), (8, 512, 512), (4, 2048, 0), (64, 16, 1024), (1, 4096, 0)):
+SHAPES = ((8, 1024, 0), (8, 512, 512), (4, 2048, 0), (64, 16, 1024), (1, 4096, 0))
+if len(sys.argv) > 2:
+    SHAPES = (SHAPES[int(sys.argv[2])], )
+for batch, n_new, ctx in SHAPES:
     T = batch * n_new
     q = torch.randn(T, H, D, dtype=torch.float16, device=dev) * 0.1
     k = torch.randn(T, Hkv, D, dtype=torch.float16, device=dev) * 0.1
