@@ -105,6 +105,8 @@ __device__ __forceinline__ float rows_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+constexpr float NEG_BIG = -1e30f;  // "minus infinity" of the running maxima and of masked logits (finite: no inf - inf)
+
 struct RowCtx {
   int qpos, g, W;
   bool row_ok, has_alibi;
@@ -124,13 +126,14 @@ __device__ __forceinline__ void softmax_pv(f32x4 (&s)[2], float& m_run, float& l
   // The accumulators o are touched in exactly one place each (the rescale and the MFMAs below), outside the
   // fast / general split: with o written on several control-flow paths hipcc shuffled all NT x 4 of them through
   // copies around every tile.
-  bool msk[2][4] = {};
   float m_tile;
   if (fast) {
     const float mx = max2(max3(max3(s[0][0], s[0][1], s[0][2]), s[0][3], s[1][0]), max3(s[1][1], s[1][2], s[1][3]));
     m_tile = rows_max(mx) * rc.scale;
   } else {
-    m_tile = -FLT_MAX;
+    // a masked logit becomes NEG_BIG: exp2 of it is exactly 0 against any finite running maximum (a row with no
+    // visible key yet - only rows past the sequence - gets finite garbage that is never stored)
+    m_tile = NEG_BIG;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -140,9 +143,9 @@ __device__ __forceinline__ void softmax_pv(f32x4 (&s)[2], float& m_run, float& l
         if (rc.W > 0 && rc.qpos - kpos >= rc.W) val = -10000.f;  // prefix_prefill.py:88-104, :201-204
         if (rc.has_alibi) val += slope_h * (float)(kpos - rc.qpos);  // :552-557
         const bool masked = kpos >= limit || (causal && kpos > rc.qpos) || !rc.row_ok;
-        msk[u][r] = masked;
+        val = masked ? NEG_BIG : val;
         s[u][r] = val;
-        m_tile = masked ? m_tile : fmaxf(m_tile, val);
+        m_tile = fmaxf(m_tile, val);
       }
     }
     m_tile = rows_max(m_tile);
@@ -161,10 +164,7 @@ __device__ __forceinline__ void softmax_pv(f32x4 (&s)[2], float& m_run, float& l
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float x = __builtin_amdgcn_exp2f(fmaf(s[u][r], c, mc));
-      e[u][r] = msk[u][r] ? 0.f : x;
-    }
+    for (int r = 0; r < 4; ++r) e[u][r] = __builtin_amdgcn_exp2f(fmaf(s[u][r], c, mc));
   u32x2 pk[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
   f32x4 os[GQ][NT];
 #pragma unroll
   for (int h = 0; h < GQ; ++h) {
-    m_runs[h] = -FLT_MAX;
+    m_runs[h] = NEG_BIG;
     l_parts[h] = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) os[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -422,17 +422,18 @@ __global__ __launch_bounds__(256) void prefill_attention_shared_kernel(const Pre
   constexpr int VROW = D * 2 + 16;           // bytes per staged new-V row (+16: rows start on different banks)
   constexpr int KIMG = 32 * KROW;            // K tile image, [key][KROW]
   constexpr int BUF = KIMG + 32 * VROW;      // one buffer: K image, then the V image
-  const int b = blockIdx.z, head0 = blockIdx.y * GQ;
+  // grid (head groups, batch, row blocks): workgroups are dispatched in linear-id order, so the row blocks - whose causal
+  // work grows with their index - are the slowest dimension and run heaviest first (longest-processing-time order: the
+  // tail of the launch is made of the 2-tile blocks, not of a 32-tile block that started last); consecutive ids are
+  // the heads / sequences of one row block, which spreads every weight class evenly over the 8 XCDs.
+  const int b = blockIdx.y, head0 = blockIdx.x * GQ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int ctx = p.b_ctx_len[b];
   const int q_len = p.b_seq_len[b] - ctx;
   const int start = p.b_start_loc[b];
-  // Causal work grows with blockIdx.x and workgroups go to the 8 XCDs round-robin by linear id: with gridDim.x a
-  // multiple of 8 XCD k would always get the same (light or heavy) row blocks. Reverse every other group of 8.
-  int xb = blockIdx.x;
-  if ((xb >> 3) & 1) xb = (xb & ~7) + min(8, (int)gridDim.x - (xb & ~7)) - 1 - (xb & 7);
+  const int xb = gridDim.z - 1 - blockIdx.z;
   const int wg_r0 = xb * 64;
   if (wg_r0 >= q_len) return;  // whole workgroup
   const int r0 = wg_r0 + wave * 16;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(256) void prefill_attention_shared_kernel(const Pre
   f32x4 os[GQ][NT];
 #pragma unroll
   for (int h = 0; h < GQ; ++h) {
-    m_runs[h] = -FLT_MAX;
+    m_runs[h] = NEG_BIG;
     l_parts[h] = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) os[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -661,7 +662,7 @@ int launch_shared(const PrefillParams& p, int batch, int max_input_len, hipStrea
   auto kern = prefill_attention_shared_kernel<scalar_t, D, GQ>;
   if (smem > 64 * 1024)
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-  dim3 grid(ceil_div(max_input_len, 64), p.num_heads / GQ, batch);
+  dim3 grid(p.num_heads / GQ, batch, ceil_div(max_input_len, 64));
   kern<<<grid, 256, smem, stream>>>(p);
   NMX_LAUNCH_CHECK();
   return NMX_OK;
@@ -679,7 +680,7 @@ int launch(const PrefillParams& p, int batch, int max_input_len, hipStream_t str
     const int group = p.num_heads / p.num_kv_heads;
     int sgq = 0;
     if (force >= 11 && fits32) sgq = force - 10;
-    else if (force == 0 && max_input_len >= 64 && fits32) sgq = (D <= 128 && group % 4 == 0) ? 4 : ((D <= 128 && group % 2 == 0) ? 2 : 1);
+    else if (force == 0 && max_input_len >= 64 && fits32 && batch <= 65535) sgq = (D <= 128 && group % 2 == 0) ? 2 : 1;
     if (sgq == 4 && (D > 128 || group % 4 != 0)) sgq = 2;
     if (sgq == 2 && (D > 128 || group % 2 != 0)) sgq = 1;
     if (sgq == 4) { if constexpr (D <= 128) return launch_shared<scalar_t, D, 4>(p, batch, max_input_len, stream); }
