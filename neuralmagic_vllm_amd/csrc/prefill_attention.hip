@@ -10,8 +10,14 @@
 //   * new V is [token][d] in memory but the product contracts over tokens: each wave stages its 32-token tile
 //     row-major in LDS (ds_write_b128) and reads it back with the gfx950 transposing LDS read
 //     (ds_read_b64_tr_b16), which hands every lane 4 tokens of its own d column per instruction.
-// One wave = 16 consecutive query tokens of one head; a workgroup = 4 such waves (64 tokens). No workgroup barrier.
-// grid (ceil(max_input_len / 64), num_heads, batch), block 256.
+// One wave = 16 consecutive query tokens of one or two heads; a workgroup = 4 such waves (64 tokens).
+// Two kernels: prefill_attention_shared_kernel (head sizes that are a multiple of 64, >= 64 new tokens) stages every
+// K / V tile once per workgroup in LDS for its four waves; prefill_attention_kernel (everything else: short chunks,
+// odd head sizes) lets every wave load its own fragments and has no workgroup barrier.
+// The softmax is VALU work beside 16 MFMAs per 32 keys, so it is kept to ~5 instructions per logit: a mask-free path
+// for tiles every row sees completely, exp2 with the scale folded into one fma, row reductions with
+// v_permlane{16,32}_swap, and a lazy running maximum (softmax_pv).
+// grid (num_heads [/ 2], batch, ceil(max_input_len / 64)), block 256.
 //
 // Compute-bound: 4 * (ctx + (i + 1)) * D flop per (query token, head); algorithmic bytes = q + out + the KV it reads.
 #include <float.h>
@@ -186,14 +192,15 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const PrefillPar
   constexpr int NT = D / 16;
   constexpr int CHUNKS = D / 8;
   constexpr int VROW = D * 2 + 16;  // bytes per staged V row (+16: rows start on different banks)
-  const int b = blockIdx.z, head0 = blockIdx.y * GQ;  // heads head0 .. head0 + GQ - 1 share one kv head
+  // grid (head groups, batch, row blocks), heaviest row blocks first (see prefill_attention_shared_kernel)
+  const int b = blockIdx.y, head0 = blockIdx.x * GQ;  // heads head0 .. head0 + GQ - 1 share one kv head
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int ctx = p.b_ctx_len[b];
   const int q_len = p.b_seq_len[b] - ctx;
   const int start = p.b_start_loc[b];
-  const int r0 = (blockIdx.x * 4 + wave) * 16;
+  const int r0 = ((gridDim.z - 1 - blockIdx.z) * 4 + wave) * 16;
   if (r0 >= q_len) return;  // whole wave: EXEC stays full for the transposing reads of the active waves
   const int kvh = head0 / (p.num_heads / p.num_kv_heads);
   const int row = r0 + li;
@@ -680,7 +687,7 @@ int launch(const PrefillParams& p, int batch, int max_input_len, hipStream_t str
     const int group = p.num_heads / p.num_kv_heads;
     int sgq = 0;
     if (force >= 11 && fits32) sgq = force - 10;
-    else if (force == 0 && max_input_len >= 64 && fits32 && batch <= 65535) sgq = (D <= 128 && group % 2 == 0) ? 2 : 1;
+    else if (force == 0 && max_input_len >= 64 && fits32) sgq = (D <= 128 && group % 2 == 0) ? 2 : 1;
     if (sgq == 4 && (D > 128 || group % 4 != 0)) sgq = 2;
     if (sgq == 2 && (D > 128 || group % 2 != 0)) sgq = 1;
     if (sgq == 4) { if constexpr (D <= 128) return launch_shared<scalar_t, D, 4>(p, batch, max_input_len, stream); }
@@ -689,13 +696,12 @@ int launch(const PrefillParams& p, int batch, int max_input_len, hipStream_t str
   }
 
   const size_t smem = (size_t)4 * 32 * (D * 2 + 16);
-  // two query heads per wave when the GQA group allows it (and the wider heads' accumulators still fit)
-  // (measured, Llama-3-8B heads: +17-20 % on 1-4 K-token prefills, equal at 512 new + 512 cached tokens; with 16 new
-  // tokens per sequence only one wave of a workgroup is active and the second head's registers just cost occupancy)
+  // two query heads per wave whenever the GQA group allows it: the K / V fragments of a tile feed twice the MFMAs
+  // (Llama-3-8B heads, 64 sequences x 16 new tokens over 1024 cached: 81 us against 175 us with one head per wave)
   const bool gq2_ok = D <= 128 && (p.num_heads / p.num_kv_heads) % 2 == 0;
-  bool gq2 = gq2_ok && max_input_len >= 256;
+  bool gq2 = gq2_ok;
   if (force == 1 || force == 2) gq2 = gq2_ok && force == 2;  // tests / sweeps: force either shape
-  dim3 grid(ceil_div(max_input_len, 64), gq2 ? p.num_heads / 2 : p.num_heads, batch);
+  dim3 grid(gq2 ? p.num_heads / 2 : p.num_heads, batch, ceil_div(max_input_len, 64));
   if (gq2) {
     if constexpr (D <= 128) {
       auto kern = prefill_attention_kernel<scalar_t, D, 2>;
@@ -747,6 +753,7 @@ extern "C" int nmx_context_attention_fwd(void* out, const void* q, const void* k
                 (uintptr_t)k_cache % 16 == 0 && (uintptr_t)v_cache % 16 == 0,
             NMX_ERR_INVALID_ARG, "context_attention_fwd: tensors must be 16-byte aligned with strides in multiples of 8");
   if (batch == 0 || max_input_len <= 0) return NMX_OK;
+  NMX_CHECK(batch <= 65535, NMX_ERR_UNSUPPORTED, "context_attention_fwd: at most 65535 sequences per call, got %d", batch);
   PrefillParams p;
   p.out = out; p.q = q; p.k = k; p.v = v; p.k_cache = k_cache; p.v_cache = v_cache;
   p.b_loc = b_loc; p.b_start_loc = b_start_loc; p.b_seq_len = b_seq_len; p.b_ctx_len = b_ctx_len;
