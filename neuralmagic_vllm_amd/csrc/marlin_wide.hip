@@ -139,7 +139,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // at the same time (28-32 requesters per line and XCD). Each workgroup therefore starts its K walk at its own offset
   // and wraps around: the sum is the same set of products, accumulated in a rotated order.
   const int n_tiles8 = (N + 64 * WN * 8 - 1) / (64 * WN * 8);
-  const int rot = (NMX_WIDE_ROT && nst > 1) ? (int)(((int64_t)(tile_x >> 3) * nst) / n_tiles8 + (block_m * nst) / (2 * m_blocks)) % nst : 0;
+  // The row blocks of one column tile walk in the SAME order: they then stream the tile's weights together and the second
+  // one hits L2 (with a per-row-block offset every row block fetched the weights from HBM again: rocprofv3 FETCH_SIZE
+  // 150 MB per gate_up launch at M = 256 against 61 MB of operands).
+  const int rot = (NMX_WIDE_ROT && nst > 1) ? (int)(((int64_t)(tile_x >> 3) * nst) / n_tiles8) % nst : 0;
   auto stage_of = [&](int rel) {                 // absolute stage of this slice's rel-th iteration (clamped past the end)
     int r = min(rel, max(nst - 1, 0)) + rot;
     r = r >= nst ? r - nst : r;
