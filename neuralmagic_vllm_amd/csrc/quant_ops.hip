@@ -7,6 +7,8 @@
 
 #include "nmx_common.h"
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
 namespace {
 
 // ---- fp8 per-tensor quant (fp8/common.cu:24-125) ----------------------------------------------------------------
@@ -433,6 +435,178 @@ __global__ __launch_bounds__(256, 2) void scaled_mm_lds_kernel(const MmParams p)
   }
 }
 
+// ---- M > 64: workgroup-tiled kernel ------------------------------------------------------------------------------------
+// The kernels above give every wave its own K slice of a 64-column tile and let it fetch both operands itself: right for
+// decode (few rows, the weight stream is the whole cost), but at M = 256 a wave issues one 1-KiB load + one LDS write +
+// one LDS read per two MFMAs and the weights are fetched once per 64-row block (gate_up fp8 at M = 256: 107 us =
+// 0.11 of the fp8 MFMA peak). Here a workgroup of WM x WN waves owns a (64 WM) x (64 WN) output tile over the whole K
+// range of its split: per 128-byte stage the operand tiles are loaded ONCE per workgroup in whole 128-byte lines (8 rows
+// per wave instruction), parked in LDS as [row][128 B] with the chunk swizzle of scaled_mm_lds_kernel, and every wave
+// reads the fragments of its 64 x 64 sub-tile: 16 ds_read_b128 per 64 (fp8) / 32 (int8) MFMAs. LDS double-buffered, the
+// next stage's global loads in flight during the MFMAs, one workgroup barrier per stage.
+// grid (ceil(N / (64 WN)), k_splits, ceil(M / (64 WM))), block 64 WM WN; LDS 2 x 64 (WM + WN) x 128 B.
+template <typename out_t, bool FP8, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmParams p) {
+  constexpr int NWAVE = WM * WN;
+  constexpr int AROWS = 64 * WM, BROWS = 64 * WN;
+  constexpr int PIECES = (AROWS + BROWS) / 8;     // 8-row x 128-byte pieces per stage
+  constexpr int PW = PIECES / NWAVE;              // per wave
+  static_assert(PIECES % NWAVE == 0, "pieces must divide over the waves");
+  constexpr int IMG = (AROWS + BROWS) * 128;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int lr = lane >> 3, lc = lane & 7;
+  const int wn = wave % WN, wm = wave / WN;
+  const int n0 = blockIdx.x * BROWS, m0 = blockIdx.z * AROWS;
+  using acc_t = typename std::conditional<FP8, f32x4, i32x4>::type;
+  acc_t acc[4][4];  // [mt][t]: rows m0 + 64 wm + 16 mt + li, columns n0 + 64 wn + 16 t + 4 g + r
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = acc_t{0, 0, 0, 0};
+
+  const int stages = p.K / 128;
+  const int per = (stages + p.k_splits - 1) / p.k_splits;
+  const int sb = min((int)blockIdx.y * per, stages), se = min(sb + per, stages);
+
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.bt), 0, (int)((int64_t)p.N * p.ldb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.a), 0, (int)((int64_t)p.M * p.lda), 0x00020000);
+  // piece q of the stage: q < AROWS / 8 -> A rows 8 q .. 8 q + 7, else B rows; image row index = the same order
+  int voff[PW], lds_off[PW];
+  bool is_a[PW];
+  auto slot = [](int r, int c) { return r * 128 + 16 * (c ^ ((r >> 1) & 7)); };
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int q = wave * PW + j;
+    const int r = 8 * q + lr;  // image row
+    is_a[j] = q < AROWS / 8;
+    if (is_a[j]) {
+      const int m = m0 + r;
+      voff[j] = m < p.M ? (int)(m * p.lda + 16 * lc) : (int)0xfffffff0u;  // rows past the matrix read as zeros
+    } else {
+      const int n = n0 + r - AROWS;
+      voff[j] = n < p.N ? (int)(n * p.ldb + 16 * lc) : (int)0xfffffff0u;
+    }
+    lds_off[j] = slot(r, lc);
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // Two register sets: the loads of stage s + 2 are issued before the MFMAs of stage s and written to LDS at the end of
+  // stage s + 1 - a whole stage of MFMAs (~1k cycles) is shorter than a loaded HBM / L2 round trip.
+  auto load = [&](int s, u32x4 (&regs)[PW]) {
+    const int soff = min(s, stages - 1) * 128;
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      regs[j] = is_a[j] ? __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff[j], soff, 0)
+                        : __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff[j], soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store = [&](char* img, const u32x4 (&regs)[PW]) {
+#pragma unroll
+    for (int j = 0; j < PW; ++j) *reinterpret_cast<u32x4*>(img + lds_off[j]) = regs[j];
+  };
+  // fp8: ONE v_mfma_scale_f32_16x16x128_f8f6f4 per (row tile, column tile) and stage - the block-scaled gfx950 form with
+  // unit scales (E8M0 127) runs e4m3 at twice the per-clock rate of v_mfma_f32_16x16x32_fp8_fp8 (which has the fp16
+  // rate: rocprofv3 counted 16 MFMA-busy cycles per instruction). Lane (g, i) supplies bytes 32 g .. 32 g + 31 of row
+  // i of the stage for both operands; the hardware's k order inside the instruction is irrelevant as long as the two
+  // operands use the same one.
+  auto compute = [&](const char* img) {
+    const char* ia = img + (64 * wm) * 128;
+    const char* ib = img + (AROWS + 64 * wn) * 128;
+    if constexpr (FP8) {
+      i32x8 bf[4], af[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(ib + slot(16 * t + li, 2 * g));
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(ib + slot(16 * t + li, 2 * g + 1));
+        bf[t] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(ia + slot(16 * mt + li, 2 * g));
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(ia + slot(16 * mt + li, 2 * g + 1));
+        af[mt] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[mt][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[t], af[mt], acc[mt][t], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {  // the two 64-byte halves of the line
+        u32x4 bf[4], af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const u32x4*>(ib + slot(16 * t + li, 4 * q + g));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(ia + slot(16 * mt + li, 4 * q + g));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[mt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bf[t]), __builtin_bit_cast(i32x4, af[mt]),
+                                                              acc[mt][t], 0, 0, 0);
+      }
+    }
+  };
+
+  if (sb < se) {
+    u32x4 ra[PW], rb[PW];
+    load(sb, ra);
+    load(sb + 1, rb);
+    store(smem, ra);
+    load(sb + 2, ra);
+    __syncthreads();
+    // stage pairs, branch-free load pattern (stages past the split are loaded clamped and never computed): at the top of
+    // an iteration LDS buffer 0 holds stage s, rb stage s + 1 (in flight), ra stage s + 2 (in flight)
+    for (int s = sb; s < se; s += 2) {
+      compute(smem);
+      store(smem + IMG, rb);
+      load(s + 3, rb);
+      __syncthreads();
+      if (s + 1 < se) compute(smem + IMG);
+      store(smem, ra);
+      load(s + 4, ra);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + 64 * wm + 16 * mt + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = n0 + 64 * wn + 16 * t + 4 * g;
+      if (n >= p.N) continue;
+      if (p.k_splits > 1) {
+        *reinterpret_cast<acc_t*>(reinterpret_cast<char*>(p.partial) + (((int64_t)blockIdx.y * p.M + m) * p.N + n) * 4) = acc[mt][t];
+      } else {
+        mm_epilogue4<out_t>(p, acc[mt][t], m, n);
+      }
+    }
+  }
+}
+
+// tile shape and K splits of scaled_mm_tile_kernel: 128 x 256 tiles when they alone give >= 128 workgroups, else
+// 128 x 128 tiles with K splits until >= 192 workgroups exist (>= 8 stages per split)
+struct TileCfg { int wn, splits; };
+inline TileCfg mm_tile_cfg(int M, int N, int K) {
+  TileCfg c{4, 1};
+  const int rows = ceil_div(M, 128), stages = K / 128;
+  if (rows * ceil_div(N, 256) >= 128) return c;
+  c.wn = 2;
+  const int tiles = rows * ceil_div(N, 128);
+  while (tiles * c.splits < 192 && c.splits < 16 && stages / (c.splits * 2) >= 8) c.splits *= 2;
+  return c;
+}
+inline bool mm_use_tile(int M, int N, int K) {
+  if (const char* e = nmx_tune(NMX_TUNE_MM_TILE)) return atoi(e) != 0 && K % 128 == 0;
+  return M > 64 && K % 128 == 0;
+}
+
 // out = epilogue(sum_s partial[s]); 4 columns per thread; summation order s = 0, 1, ... (deterministic)
 template <typename out_t, bool FP8>
 __global__ void scaled_mm_reduce_kernel(const MmParams p) {
@@ -457,7 +631,38 @@ inline int mm_splits(int M, int N, int K) {
 }
 
 template <typename out_t, bool FP8>
+int launch_mm_tile(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+  const TileCfg c = mm_tile_cfg(p.M, p.N, p.K);
+  p.k_splits = c.splits;
+  const int64_t per = (int64_t)p.M * p.N * 4;
+  if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to what fits
+    const int fit = scratch == nullptr ? 1 : (int)std::min<int64_t>(p.k_splits, scratch_bytes / per);
+    p.k_splits = std::max(1, fit);
+  }
+  p.partial = scratch;
+  dim3 grid(ceil_div(p.N, 64 * c.wn), p.k_splits, ceil_div(p.M, 128));
+  const int smem = 2 * 64 * (2 + c.wn) * 128;
+  if (c.wn == 4) {
+    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 4>;
+    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    kern<<<grid, 512, smem, stream>>>(p);
+  } else {
+    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 2>;
+    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    kern<<<grid, 256, smem, stream>>>(p);
+  }
+  NMX_LAUNCH_CHECK();
+  if (p.k_splits > 1) {
+    const int64_t mn4 = (int64_t)p.M * p.N / 4;
+    scaled_mm_reduce_kernel<out_t, FP8><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(p);
+    NMX_LAUNCH_CHECK();
+  }
+  return NMX_OK;
+}
+
+template <typename out_t, bool FP8>
 int launch_mm(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+  if (mm_use_tile(p.M, p.N, p.K)) return launch_mm_tile<out_t, FP8>(p, scratch, scratch_bytes, stream);
   const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
   p.k_splits = mm_splits(p.M, p.N, p.K);
   const int64_t per = (int64_t)p.M * p.N * 4;
@@ -565,7 +770,7 @@ extern "C" int nmx_scaled_int8_quant(void* out, const void* input, float* scales
 
 extern "C" int64_t nmx_scaled_mm_scratch_bytes(int m, int n, int k) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
-  const int sp = mm_splits(m, n, k);
+  const int sp = mm_use_tile(m, n, k) ? mm_tile_cfg(m, n, k).splits : mm_splits(m, n, k);
   return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
 }
 

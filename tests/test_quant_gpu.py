@@ -93,6 +93,33 @@ def test_cutlass_scaled_mm(ops, m, n, k, per_act_token, per_out_ch, is_fp8, use_
     torch.testing.assert_close(out.cpu().float(), orc.float(), rtol=1e-2, atol=2e-2 if is_fp8 else 1e-1)
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 16384, 1024), (129, 16400, 256), (300, 1104, 2048), (256, 6144, 4096), (65, 64, 128)])
+@pytest.mark.parametrize("is_fp8", [True, False])
+@pytest.mark.parametrize("tile", [None, "0"])
+def test_scaled_mm_tile_kernel(ops, tune, m, n, k, is_fp8, tile):
+    """M > 64: scaled_mm_tile_kernel (128 x 256 tiles when they fill the chip, else 128 x 128 with K splits), ragged M / N,
+    per-row and per-column scales with bias; checked against the fp32 product computed on the device and against the
+    per-wave kernel (NMX_MM_TILE=0) through the same bar. int8 accumulates exactly: the two kernels must agree bit for bit."""
+    seed_all(5)
+    out_dtype = torch.bfloat16 if is_fp8 else torch.float16
+    if is_fp8:
+        a = to_fp8(torch.randn(m, k)).to(DEV)
+        b = to_fp8(torch.randn(n, k)).to(DEV)
+    else:
+        a = to_int8(torch.randn(m, k) * 5).to(DEV)
+        b = to_int8(torch.randn(n, k) * 5).to(DEV)
+    sa = (torch.rand(m, 1) / 10 + 0.01).to(DEV)
+    sb = (torch.rand(1, n) / 10 + 0.01).to(DEV)
+    bias = (torch.rand(n) * 10).to(out_dtype).to(DEV)
+    tune(NMX_MM_TILE=tile)
+    out = ops.cutlass_scaled_mm(a, b.t(), sa, sb, out_dtype, bias)
+    base = (sa * (sb * torch.mm(a.float(), b.float().t()))).to(out_dtype) + bias
+    torch.testing.assert_close(out, base, rtol=1e-2, atol=5e-2 if is_fp8 else 1e-1)
+    if not is_fp8 and tile is None:
+        tune(NMX_MM_TILE="0")
+        assert torch.equal(out, ops.cutlass_scaled_mm(a, b.t(), sa, sb, out_dtype, bias))
+
+
 def test_scaled_mm_errors(ops):
     a = torch.zeros(4, 32, dtype=torch.int8, device=DEV)
     b = torch.zeros(32, 16, dtype=torch.int8, device=DEV)  # row-major: must be rejected
