@@ -97,6 +97,8 @@ def parse():
                     "rotary / reshape_and_cache) instead of the fused consumers - bit-identical results, more launches")
     ap.add_argument("--awq-op", action="store_true", help="AWQ configs: call the checkpoint-layout awq_gemm op instead of the "
                     "load-time repack + zero-point Marlin kernel that AWQLinearMethod uses")
+    ap.add_argument("--attn", choices=["auto", "v1", "v2"], default="auto", help="decode attention op: auto = the reference's rule "
+                    "(paged_attn.py:120-121)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
@@ -141,7 +143,7 @@ class Llama3Decode:
     """Synthetic Llama-3-8B decode step driver (the *caller* of the hot path; stands in for vllm's LlamaForCausalLM)."""
 
     def __init__(self, ops, cfg, batch, ctx, n_layers, device, block_size=16, variant="int4", all_reduce=None, all_gather=None,
-                 awq_marlin=True):
+                 awq_marlin=True, attn="auto"):
         self.ops, self.cfg, self.B, self.L, self.dev = ops, cfg, batch, ctx, device
         self.awq_marlin = awq_marlin  # AWQ configs: weights repacked at load (the layer's path); False = the raw awq_gemm op
         self.all_reduce, self.all_gather = all_reduce, all_gather  # tensor-parallel collectives (None: TP = 1)
@@ -202,6 +204,8 @@ class Llama3Decode:
         # v2 temporaries (vllm/attention/ops/paged_attn.py:148-158)
         self.P = (ctx + 511) // 512
         self.use_v1 = ctx <= 8192 and (self.P == 1 or batch * nh > 512)  # paged_attn.py:120-121
+        if attn != "auto":
+            self.use_v1 = attn == "v1"
         if not self.use_v1:
             self.tmp_out = torch.empty(batch, nh, self.P, D, dtype=torch.float16, device=device)
             self.exp_sums = torch.empty(batch, nh, self.P, dtype=torch.float32, device=device)
@@ -538,7 +542,7 @@ def main():
         dist.all_reduce(warm)  # communicator set-up outside the capture
         torch.cuda.synchronize()
     model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev, variant=args.config, all_reduce=all_reduce,
-                         all_gather=all_gather, awq_marlin=not args.awq_op)
+                         all_gather=all_gather, awq_marlin=not args.awq_op, attn=args.attn)
 
     model.fuse = args.config == "int4" and not args.no_fuse
     model.step()  # eager once: allocates GEMM scratch outside capture

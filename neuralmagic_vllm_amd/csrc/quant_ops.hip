@@ -444,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void scaled_mm_lds_kernel(const MmParams p)
 // per wave instruction), parked in LDS as [row][128 B] with the chunk swizzle of scaled_mm_lds_kernel, and every wave
 // reads the fragments of its 64 x 64 sub-tile: 16 ds_read_b128 per 64 (fp8) / 32 (int8) MFMAs. LDS double-buffered, the
 // next stage's global loads in flight during the MFMAs, one workgroup barrier per stage.
-// grid (ceil(N / (64 WN)), k_splits, ceil(M / (64 WM))), block 64 WM WN; LDS 2 x 64 (WM + WN) x 128 B.
-template <typename out_t, bool FP8, int WM, int WN>
+// grid (ceil(N / (64 WN)), k_splits, ceil(M / (64 WM))), block 64 WM WN; LDS NBUF x 64 (WM + WN) x 128 B.
+template <typename out_t, bool FP8, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmParams p) {
   constexpr int NWAVE = WM * WN;
   constexpr int AROWS = 64 * WM, BROWS = 64 * WN;
@@ -476,7 +476,14 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
   // piece q of the stage: q < AROWS / 8 -> A rows 8 q .. 8 q + 7, else B rows; image row index = the same order
   int voff[PW], lds_off[PW];
   bool is_a[PW];
-  auto slot = [](int r, int c) { return r * 128 + 16 * (c ^ ((r >> 1) & 7)); };
+  // chunk swizzle inside a 128-byte row: the writes (8 lanes = one row's 8 chunks) are conflict-free under any per-row
+  // XOR; the fragment reads differ: int8 reads chunk 4 q + g of 16 consecutive rows (XOR with (r >> 1) & 7), fp8 reads
+  // chunks 2 g and 2 g + 1 (XOR with 2 ((r >> 1) & 3) + ((r >> 3) & 1): found by exhaustive search over the ds_read_b128
+  // lane groups; with the int8 swizzle the fp8 reads were 2-way conflicted, SQ_LDS_BANK_CONFLICT = 2.9 cycles per read)
+  auto slot = [](int r, int c) {
+    const int f = FP8 ? (2 * ((r >> 1) & 3) + ((r >> 3) & 1)) : ((r >> 1) & 7);
+    return r * 128 + 16 * (c ^ f);
+  };
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
     const int q = wave * PW + j;
@@ -495,8 +502,16 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
 
   // Two register sets: the loads of stage s + 2 are issued before the MFMAs of stage s and written to LDS at the end of
   // stage s + 1 - a whole stage of MFMAs (~1k cycles) is shorter than a loaded HBM / L2 round trip.
+  // Every workgroup reads byte columns [128 s, 128 s + 128) of rows that are K (a power of two) bytes apart: walking s in
+  // the same order everywhere sends all of them to the same few HBM channels / L2 lines at the same time. Each column tile
+  // therefore starts its walk at its own stage and wraps (the row blocks of a column tile share the order so that they
+  // share the weight lines in L2); the sum is the same set of products in a rotated order.
+  const int nst = se - sb;
+  const int rot = nst > 1 ? (int)((blockIdx.x * 11u) % (unsigned)nst) : 0;
   auto load = [&](int s, u32x4 (&regs)[PW]) {
-    const int soff = min(s, stages - 1) * 128;
+    int r = min(s - sb, nst - 1) + rot;  // past the split: a valid stage again (never computed)
+    r = r >= nst ? r - nst : r;
+    const int soff = (sb + r) * 128;
 #pragma unroll
     for (int j = 0; j < PW; ++j)
       regs[j] = is_a[j] ? __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff[j], soff, 0)
@@ -560,16 +575,26 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
     load(sb + 2, ra);
     __syncthreads();
     // stage pairs, branch-free load pattern (stages past the split are loaded clamped and never computed): at the top of
-    // an iteration LDS buffer 0 holds stage s, rb stage s + 1 (in flight), ra stage s + 2 (in flight)
+    // an iteration the LDS holds stage s, rb stage s + 1 (in flight), ra stage s + 2 (in flight).
+    // NBUF = 3: stage s + 1 goes to a THIRD buffer before the MFMAs of stage s, so the LDS writes (about as long as the
+    // fragment reads: the write path moves 64 B/clk) run under the MFMAs instead of after them; NBUF = 2 (the 4-wave
+    // tile, two workgroups per CU) writes after the MFMAs into the buffer the previous stage has released.
+    int cur = 0;
     for (int s = sb; s < se; s += 2) {
-      compute(smem);
-      store(smem + IMG, rb);
-      load(s + 3, rb);
+      const int n1 = cur + 1 == NBUF ? 0 : cur + 1, n2 = n1 + 1 == NBUF ? 0 : n1 + 1;
+      if constexpr (NBUF == 3) store(smem + n1 * IMG, rb);
+      if constexpr (NBUF == 3) load(s + 3, rb);
+      compute(smem + cur * IMG);
+      if constexpr (NBUF == 2) store(smem + n1 * IMG, rb);
+      if constexpr (NBUF == 2) load(s + 3, rb);
       __syncthreads();
-      if (s + 1 < se) compute(smem + IMG);
-      store(smem, ra);
-      load(s + 4, ra);
+      if constexpr (NBUF == 3) store(smem + n2 * IMG, ra);
+      if constexpr (NBUF == 3) load(s + 4, ra);
+      if (s + 1 < se) compute(smem + n1 * IMG);
+      if constexpr (NBUF == 2) store(smem + n2 * IMG, ra);
+      if constexpr (NBUF == 2) load(s + 4, ra);
       __syncthreads();
+      cur = n2;
     }
   }
 
@@ -596,7 +621,9 @@ struct TileCfg { int wn, splits; };
 inline TileCfg mm_tile_cfg(int M, int N, int K) {
   TileCfg c{4, 1};
   const int rows = ceil_div(M, 128), stages = K / 128;
-  if (rows * ceil_div(N, 256) >= 128) return c;
+  int force = 0;  // NMX_MM_TILE=2 / 4: force the 128-column / 256-column tile (sweeps)
+  if (const char* e = nmx_tune(NMX_TUNE_MM_TILE)) force = atoi(e);
+  if (force != 2 && (force == 4 || rows * ceil_div(N, 256) >= 128)) return c;
   c.wn = 2;
   const int tiles = rows * ceil_div(N, 128);
   while (tiles * c.splits < 192 && c.splits < 16 && stages / (c.splits * 2) >= 8) c.splits *= 2;
@@ -641,13 +668,13 @@ int launch_mm_tile(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
   }
   p.partial = scratch;
   dim3 grid(ceil_div(p.N, 64 * c.wn), p.k_splits, ceil_div(p.M, 128));
-  const int smem = 2 * 64 * (2 + c.wn) * 128;
+  const int smem = (c.wn == 4 ? 3 : 2) * 64 * (2 + c.wn) * 128;
   if (c.wn == 4) {
-    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 4>;
+    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 4, 3>;
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     kern<<<grid, 512, smem, stream>>>(p);
   } else {
-    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 2>;
+    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 2, 2>;
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     kern<<<grid, 256, smem, stream>>>(p);
   }
