@@ -48,6 +48,13 @@ def _dev(t: torch.Tensor) -> None:
 
 
 def _stream(t: torch.Tensor) -> c_vp:
+    # One process per GPU: the library launches on the CURRENT HIP device (kernel attributes, error state, scratch are
+    # per device). The reference wraps every op in an OptionalCUDAGuard (e.g. gptq_marlin.cu:1745); here a tensor on
+    # another device is refused loudly instead of being launched against the wrong device's state.
+    idx = t.device.index
+    if idx is not None and idx != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "wrap the call in torch.cuda.device(tensor.device)")
     return c_vp(torch.cuda.current_stream(t.device).cuda_stream)
 
 

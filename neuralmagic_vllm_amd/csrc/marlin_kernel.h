@@ -1706,7 +1706,7 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
   if constexpr (!SP) {
     // M > 64, plain layout: 128-row wave tiles (marlin_wide.hip)
     NmxWideCfg wc;
-    if (p.perm == nullptr && !p.slow_act_order && nmx_wide_pick(p.M, p.N, p.K, p.num_groups, p.group_size, &wc)) {
+    if (p.perm == nullptr && !p.slow_act_order && nmx_wide_pick(p.M, p.N, p.K, p.num_groups, p.group_size, &wc, KIND)) {
       NmxWideCall call;
       call.a = p.a; call.b = p.b; call.scales = p.scales; call.c = p.c; call.scratch = scratch; call.scratch_bytes = scratch_bytes;
       call.M = p.M; call.N = p.N; call.K = p.K; call.num_groups = p.num_groups; call.group_size = p.group_size;

@@ -92,20 +92,20 @@ __device__ __forceinline__ void dq_op(const u32x2& q0, const u32x2& q1, const u3
   }
 }
 
-template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK>
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MTP>
 __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const GemmParams p) {
   constexpr bool I4 = (KIND == W_INT4);
   constexpr bool FAST = I4 && __is_same(scalar_t, f16);  // hand-placed conversion; other kinds: compiler-scheduled
   constexpr bool SCALED = (MODE == 1);
-  constexpr int MT = 8;                         // 16-row MFMA tiles per wave
+  constexpr int MT = MTP;                       // 16-row MFMA tiles per wave: 8 (128-row wave tile) or 4 (64 rows, M <= 64)
   constexpr int NTILE = 4;                      // 16-column MFMA tiles per wave
-  constexpr int BM = 128 * WM;
+  constexpr int BM = 16 * MT * WM;
   constexpr int TS = 64 * WM * WN;              // threads of one K-slice
   constexpr int NA = BM * 8 / TS;               // 16-byte activation pieces per thread and 64-k stage
   constexpr int A_IMG = BM * 128;               // bytes of one stage image [k-step 2][g 4][row BM][16 B]
   constexpr int WORDS64 = I4 ? 128 : 256;       // int32 per (k-tile, 64-column group)
   // load issue order per iteration: [batch(s + 2)] [W(2 s + 5)] [W(2 s + 6)]; hipcc derives the counted vmcnt waits
-  static_assert(NA == 4 || NA == 8, "activation pieces per thread");
+  static_assert((NA == 2 || NA == 4 || NA == 8) && NA <= MT, "activation pieces per thread");
   using bvec_t = typename std::conditional<I4, u32x2, u32x4>::type;
 
   const int lane = threadIdx.x & 63;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   };
 
   const uint32_t magic = 0x64006400u, neg72 = 0xd480d480u;
-  const char* const r_base0 = abuf + (g * BM + wm * 128 + li) * 16;
-  const char* const r_base1 = abuf + ((4 + g) * BM + wm * 128 + (li ^ 4)) * 16;
+  const char* const r_base0 = abuf + (g * BM + wm * 16 * MT + li) * 16;
+  const char* const r_base1 = abuf + ((4 + g) * BM + wm * 16 * MT + (li ^ 4)) * 16;
 
   // One k-step of a stage: 32 MFMAs on fragments `cur` x the 8 activation fragments of (buf, KS); in their shadows the
   // conversion of the NEXT k-step's packed words `nxt` into `out`, the fragment reads 4 row tiles ahead (KS = 0: running
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       // a CU retires roughly one vector-memory wave instruction per ~38 cycles, and a burst of 13 per wave from all
       // eight waves at the same point of the loop left the matrix pipes idle meanwhile
       if constexpr (LAND) {
-        constexpr int STEP = 8 / NA;
+        constexpr int STEP = MT / NA;
         if (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
         if (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
         if (mt == 1) issue_w(2 * st + 5, refill);
@@ -331,12 +331,15 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) wq[t] = u32x4{cur.w[t][0], cur.w[t][1], cur.w[t][2], cur.w[t][3]};
     constexpr int NOPS = DqPlan<SCALED>::TOTAL;
-    auto ops = [&](auto i_c) {  // the two conversion operations behind MFMA number i
+    constexpr int OPM = (NOPS + MT * NTILE - 1) / (MT * NTILE);  // conversion operations per MFMA: 2 (MT = 8) / 3-4 (MT = 4)
+    auto ops = [&](auto i_c) {  // the conversion operations behind MFMA number i
       constexpr int I = decltype(i_c)::value;
       if constexpr ((NMX_WABLATE & 2) == 0) {
         if constexpr (I4) {
-          if constexpr (2 * I < NOPS) dq_op<SCALED, 2 * I>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
-          if constexpr (2 * I + 1 < NOPS) dq_op<SCALED, 2 * I + 1>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
+          if constexpr (OPM * I < NOPS) dq_op<SCALED, OPM * I>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
+          if constexpr (OPM * I + 1 < NOPS) dq_op<SCALED, OPM * I + 1>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
+          if constexpr (OPM > 2 && OPM * I + 2 < NOPS) dq_op<SCALED, OPM * I + 2>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
+          if constexpr (OPM > 3 && OPM * I + 3 < NOPS) dq_op<SCALED, OPM * I + 3>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
         }
       }
     };
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         else if constexpr (KS == 0) af[MT + (mt + 4 - MT)] = *reinterpret_cast<const u32x4*>(rb1 + (mt + 4 - MT) * 256);
       }
       if constexpr (LAND) {  // see kstep_block
-        constexpr int STEP = 8 / NA;
+        constexpr int STEP = MT / NA;
         if constexpr (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
         if constexpr (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
         if constexpr (mt == 1) issue_w(2 * st + 5, refill);
@@ -365,10 +368,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     row(std::integral_constant<int, 1>{});
     row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{});
-    row(std::integral_constant<int, 4>{});
-    row(std::integral_constant<int, 5>{});
-    row(std::integral_constant<int, 6>{});
-    row(std::integral_constant<int, 7>{});
+    if constexpr (MT > 4) {
+      row(std::integral_constant<int, 4>{});
+      row(std::integral_constant<int, 5>{});
+      row(std::integral_constant<int, 6>{});
+      row(std::integral_constant<int, 7>{});
+    }
     if constexpr (LAND) load_piece(NA - 1, st + 2);
   };
 
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // lane (g, li): D rows = 4 consecutive output columns 32 (g >> 1) + 8 t + 4 (g & 1) + r, D col = activation row li
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + wm * 128 + mt * 16 + li;
+    const int m = m0 + wm * 16 * MT + mt * 16 + li;
     if (m >= M) continue;
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
@@ -498,14 +503,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   }
 }
 
-template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK>
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MT = 8>
 int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
-  constexpr int BM = 128 * WM;
+  constexpr int BM = 16 * MT * WM;
   const size_t stage = (size_t)WK * 2 * BM * 128;
-  const size_t red = (WK > 1) ? (size_t)(WK / 2) * WM * WN * 8 * 4 * 64 * 4 * sizeof(float) : 0;
+  const size_t red = (WK > 1) ? (size_t)(WK / 2) * WM * WN * MT * 4 * 64 * 4 * sizeof(float) : 0;
   const size_t smem = std::max(stage, red);
   dim3 grid(ceil_div(ceil_div(p.N, 64 * WN), 8) * 8 * ceil_div(p.M, BM), p.k_splits, 1);
-  auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK>;
+  auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK, MT>;
   if (smem > 64 * 1024)
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   kern<<<grid, 64 * WM * WN * WK, smem, stream>>>(p);
@@ -515,6 +520,14 @@ int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename scalar_t, int KIND, int MODE>
 int launch_wide_shape(const GemmParams& p, const NmxWideCfg& c, hipStream_t stream) {
+  if (c.mt == 4) {  // 64-row wave tiles (M <= 64): int4 only
+    if constexpr (KIND == W_INT4) {
+      if (c.wn == 2) return launch_wide_cfg<scalar_t, KIND, MODE, 1, 2, 4, 4>(p, stream);
+      return launch_wide_cfg<scalar_t, KIND, MODE, 1, 4, 2, 4>(p, stream);
+    } else {
+      return NMX_ERR_UNSUPPORTED;
+    }
+  }
   if (c.wm == 2 && c.wn == 2) return launch_wide_cfg<scalar_t, KIND, MODE, 2, 2, 2>(p, stream);
   if (c.wm == 2 && c.wn == 4) return launch_wide_cfg<scalar_t, KIND, MODE, 2, 4, 1>(p, stream);
   if (c.wm == 1 && c.wn == 2) return launch_wide_cfg<scalar_t, KIND, MODE, 1, 2, 4>(p, stream);
@@ -533,30 +546,40 @@ int launch_wide_kind(const GemmParams& p, const NmxWideCfg& c, hipStream_t strea
 // NMX_GEMM_WIDE = "wm,wn,splits" forces a configuration, "0" disables the kernel (sweeps and tests)
 struct WideEnv {
   bool set = false, off = false;
-  int wm = 0, wn = 0, splits = 0;
+  int wm = 0, wn = 0, splits = 0, mt = 8;
 };
 WideEnv wide_env() {
   WideEnv w;
   const char* e = nmx_tune(NMX_TUNE_GEMM_WIDE);
   if (e == nullptr) return w;
-  int a = 0, b = 0, s = 0;
-  const int got = sscanf(e, "%d,%d,%d", &a, &b, &s);
+  int a = 0, b = 0, s = 0, m = 8;
+  const int got = sscanf(e, "%d,%d,%d,%d", &a, &b, &s, &m);
   if (got == 1 && a == 0) { w.off = true; return w; }
-  if (got == 3 && (a == 1 || a == 2) && (b == 2 || b == 4) && s >= 1 && s <= 32) { w.set = true; w.wm = a; w.wn = b; w.splits = s; }
+  if (got >= 3 && (a == 1 || a == 2) && (b == 2 || b == 4) && s >= 1 && s <= 32) {
+    w.set = true; w.wm = a; w.wn = b; w.splits = s;
+    w.mt = (got == 4 && m == 4 && a == 1) ? 4 : 8;
+  }
   return w;
 }
 
 }  // namespace
 
-bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg) {
+bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg, int kind) {
   const WideEnv env = wide_env();
-  if (env.off || M <= 64 || K % 64 != 0 || N % 64 != 0) return false;
+  if (env.off || K % 64 != 0 || N % 64 != 0) return false;
+  // M <= 64: the 64-row instantiation wins only where 128-column tiles alone fill the chip and K is short (gate_up at
+  // 32 < M <= 64: 29.3 vs 34.5 us); qkv / o / down need K splits and stay on the row-block / decode kernels
+  const bool small_ok = M > 32 && K <= 8192 && ceil_div(N, 128) >= 192;
+  if (M <= 64 && (kind != W_INT4 || !(env.set ? env.mt == 4 : small_ok))) return false;  // 64-row tiles: int4 only
   if (num_groups > 1 && group_size % 64 != 0) return false;
   if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)K * N >= (1ll << 31) || (int64_t)num_groups * N * 2 >= (1ll << 31)) return false;
   NmxWideCfg c;
   const int stages = K / 64;
+  c.mt = 8;
   if (env.set) {
-    c.wm = env.wm; c.wn = env.wn; c.splits = env.splits;
+    c.wm = env.wm; c.wn = env.wn; c.splits = env.splits; c.mt = (M <= 64 || kind == W_INT4) ? env.mt : 8;
+  } else if (M <= 64) {
+    c.wm = 1; c.wn = 2; c.splits = 1; c.mt = 4;
   } else {
     // Measured (tools/lean_sweep.py, 32-launch graph chains over distinct weights, Llama-3-8B shapes, M = 128 .. 2048;
     // gpurun_out/wide_sweep.log): 128-row x 256-column tiles with two K slices per workgroup win 13-23 % over the 64-row

@@ -20,8 +20,8 @@ struct NmxWideCall {
 };
 
 // tile configuration of marlin_wide_kernel: wm x wn x wk waves, `splits` K splits across workgroups
-struct NmxWideCfg { int wm, wn, wk, splits; };
+struct NmxWideCfg { int wm, wn, wk, splits, mt; };  // mt = 16-row tiles per wave (8; 4 = 64-row wave tiles)
 
 // true when the wide kernel handles this problem (M large enough, plain layout); fills the configuration
-__attribute__((visibility("hidden"))) bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg);
+__attribute__((visibility("hidden"))) bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg, int kind = 0);  // kind: WeightKind (0 = int4)
 __attribute__((visibility("hidden"))) int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream);

@@ -47,6 +47,21 @@ def test_wide_forced_tiles(ops, tune, wide, m, K, N, group):
     assert compute_max_diff(run(ops, a, q, s, K, N), a.float() @ w_ref) < TOL
 
 
+@pytest.mark.parametrize("wide", ["1,2,1,4", "1,2,3,4", "1,4,1,4", "1,4,2,4"])
+@pytest.mark.parametrize("m", [1, 16, 33, 64])
+@pytest.mark.parametrize("K,N,group", [(1536, 320, 128), (1088, 512, -1), (1024, 192, 64)])
+def test_wide_64_row_tiles(ops, tune, wide, m, K, N, group):
+    """The 64-row wave-tile instantiation (fourth NMX_GEMM_WIDE field = 4; int4, M <= 64)."""
+    w_ref, q, s = make(K, N, group)
+    seed_all(m)
+    a = torch.randn(m, K, dtype=torch.float16)
+    tune(NMX_GEMM_WIDE=wide)
+    assert compute_max_diff(run(ops, a, q, s, K, N), a.float() @ w_ref) < TOL
+    w_ref, q, s = make(K, N, group, 4, torch.bfloat16, seed=2)
+    ab = torch.randn(m, K, dtype=torch.bfloat16)
+    assert compute_max_diff(run(ops, ab, q, s, K, N), ab.float() @ w_ref) < 4e-3
+
+
 @pytest.mark.parametrize("wide", ["1,2,2", "2,2,1", "2,4,2"])
 @pytest.mark.parametrize("bits,group", [(8, 128), (8, -1), (4, 128)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
