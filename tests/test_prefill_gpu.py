@@ -91,6 +91,33 @@ def test_two_heads_per_wave_shape(ops, tune, gq, heads, head_size):
     torch.testing.assert_close(run_hip(c).float(), run_oracle(c).float(), atol=2e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_long_ragged_prompts(ops, dtype):
+    """Many key tiles per workgroup, ragged lengths in one launch (a 1 500-token prompt over 700 cached tokens next to short
+    ones): the double-buffered LDS tiles, the block-table prefetch across the cached / new boundary and the
+    heaviest-first grid order of the shared kernel, GQA 8 : 2, head 128."""
+    seed_all(7)
+    random.seed(7)
+    c = make_case(4, 8, 2, 128, 16, dtype, max_q=1500, max_ctx=700, min_len=1400, cache_blocks=512)
+    # make the batch ragged: one long, one medium, two short sequences
+    lens = [1500, 300, 65, 1]
+    ctxs = [700, 0, 333, 15]
+    T = sum(lens)
+    for n in ("q", "k", "v"):
+        c[n] = c[n][:T]
+    c["b_start_loc"] = torch.tensor([0, 1500, 1800, 1865], dtype=torch.int32)
+    c["b_seq_len"] = torch.tensor([a + b for a, b in zip(lens, ctxs)], dtype=torch.int32)
+    c["b_ctx_len"] = torch.tensor(ctxs, dtype=torch.int32)
+    c["max_input_len"] = 1500
+    for n in ("k_cache", "v_cache"):  # make_case poisoned slots for ITS context lengths; ours differ
+        c[n] = torch.nan_to_num(c[n].float(), nan=0.25).to(dtype)
+    out = run_hip(c)
+    orc = run_oracle(c)
+    assert not torch.isnan(out).any()
+    tol = dict(atol=2e-3, rtol=2e-3) if dtype == torch.float16 else dict(atol=1.5e-2, rtol=1.5e-2)
+    torch.testing.assert_close(out.float(), orc.float(), **tol)
+
+
 @pytest.mark.parametrize("block_size", [8, 16, 32])
 @pytest.mark.parametrize("head_size", [80, 112, 192, 256])
 def test_contexted_kv_attention_alibi_and_shapes(ops, block_size, head_size):
