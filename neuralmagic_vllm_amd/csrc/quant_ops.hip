@@ -9,6 +9,12 @@
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
+// timing ablations of scaled_mm_tile_kernel (results are WRONG when set; never defined in the product build):
+// bit 0 skip global loads, 1 skip MFMAs, 2 skip LDS writes, 3 skip LDS fragment reads, 4 skip barriers
+#ifndef NMX_TABLATE
+#define NMX_TABLATE 0
+#endif
+
 namespace {
 
 // ---- fp8 per-tensor quant (fp8/common.cu:24-125) ----------------------------------------------------------------
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
     int r = min(s - sb, nst - 1) + rot;  // past the split: a valid stage again (never computed)
     r = r >= nst ? r - nst : r;
     const int soff = (sb + r) * 128;
+    if constexpr ((NMX_TABLATE & 1) != 0) return;
 #pragma unroll
     for (int j = 0; j < PW; ++j)
       regs[j] = is_a[j] ? __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff[j], soff, 0)
@@ -519,6 +526,7 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
     __builtin_amdgcn_sched_barrier(0);
   };
   auto store = [&](char* img, const u32x4 (&regs)[PW]) {
+    if constexpr ((NMX_TABLATE & 4) != 0) return;
 #pragma unroll
     for (int j = 0; j < PW; ++j) *reinterpret_cast<u32x4*>(img + lds_off[j]) = regs[j];
   };
@@ -567,8 +575,60 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
     }
   };
 
+  // ---- fp8, three LDS buffers: LDS-DMA staging -------------------------------------------------------------------------------
+  // Timing ablations of the register-staged loop (gate_up, M = 256, 45.9 us): without the LDS writes 33.4, without the
+  // global loads 37.0, without the MFMAs 41.2, MFMAs + barriers alone 27.0 - the ds_write_b128 pass (64 B/clk write path,
+  // 48 KiB per stage and CU) was the largest removable term. `buffer_load_dwordx4 ... lds` deposits a wave instruction's
+  // 8 rows x 128 B straight into the image (lane l -> base + 16 l, so the chunk swizzle moves to the SOURCE address: lane
+  // (row lr, slot lc) fetches chunk lc ^ f(row)); no staging registers, no LDS store instructions. The DMA of stage
+  // j + 2 is issued before the MFMAs of stage j; a counted vmcnt lets it stay in flight across the raw s_barrier that
+  // publishes stage j + 1 (a __syncthreads() would drain it: its fence waits vmcnt(0) while an LDS-DMA is pending).
+  int gvoff[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int q = wave * PW + j;
+    const int r = 8 * q + lr;  // image row of this lane's piece
+    const int f = 2 * ((r >> 1) & 3) + ((r >> 3) & 1);
+    const int c = lc ^ f;
+    if (q < AROWS / 8) gvoff[j] = (int)(min(m0 + r, p.M - 1) * p.lda + 16 * c);   // rows past the matrix: a valid row again,
+    else gvoff[j] = (int)(min(n0 + r - AROWS, p.N - 1) * p.ldb + 16 * c);         // its outputs are never stored
+  }
+  auto dma = [&](int s, char* img) {
+    int r = min(s - sb, nst - 1) + rot;
+    r = r >= nst ? r - nst : r;
+    const int soff = (sb + r) * 128;
+    if constexpr ((NMX_TABLATE & 1) != 0) return;
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the kernel's stub; it has no LDS address space to cast to
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      auto* dst = (__attribute__((address_space(3))) void*)(img + (wave * PW + j) * 1024);
+      if (is_a[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, gvoff[j], soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst, 16, gvoff[j], soff, 0, 0);
+    }
+#endif
+  };
+
   if (sb < se) {
     u32x4 ra[PW], rb[PW];
+    // (with two buffers - one stage of lookahead, vmcnt(0) at every barrier - the DMA form measured 10-20 % SLOWER than the
+    // two-register-set pipeline below, which keeps two stages of loads in flight: three buffers only)
+    if constexpr (FP8 && NBUF == 3) {
+      constexpr int LA = NBUF - 1;  // stages of DMA lookahead
+      dma(sb, smem);
+      if constexpr (LA == 2) dma(sb + 1, smem + IMG);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (LA - 1)) : "memory");  // stage 0 landed everywhere
+      int cur = 0;
+      for (int s = sb; s < se; ++s) {
+        int nb = cur + LA;
+        nb = nb >= NBUF ? nb - NBUF : nb;
+        dma(s + LA, smem + nb * IMG);  // the buffer stage s - 1 released at the last barrier
+        compute(smem + cur * IMG);
+        // own fragment reads done (the buffer is overwritten next stage), stage s + 1 landed (all but the newest DMAs)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW * (LA - 1)) : "memory");
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped DMAs past the split: nothing may land after the exit
+    } else {
     load(sb, ra);
     load(sb + 1, rb);
     store(smem, ra);
@@ -595,6 +655,7 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
       if constexpr (NBUF == 2) load(s + 4, ra);
       __syncthreads();
       cur = n2;
+    }
     }
   }
 
