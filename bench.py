@@ -281,12 +281,45 @@ class Llama3Decode:
         self.next_tokens.copy_(logits.argmax(-1))
         return self.next_tokens
 
+    def step_fused_fp8(self):
+        """fp8 config with 4 launches per layer less: the norm / activation in front of every fp8 linear layer leaves the
+        per-token |max| of its output, so the dynamic activation quantisation is one launch instead of absmax + quantise
+        (scaled_fp8_quant_partials: same scale and codes), and rotary + KV-cache write are one launch. o_proj's input
+        comes out of paged attention and keeps the two-launch quantisation."""
+        cfg, ops = self.cfg, self.ops
+        nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
+
+        def mm(x, amax, w):
+            qx, sx = ops.scaled_fp8_quant_partials(x, amax) if amax is not None else ops.scaled_fp8_quant(x)
+            return ops.cutlass_scaled_mm(qx, w[0], sx, w[1], torch.float16)
+
+        h = self.embed[self.tokens]
+        resid = h
+        x = torch.empty_like(h)
+        amax = ops.rms_norm_absmax(x, h, self.layers[0]["ln1"], 1e-5)
+        for li, lw in enumerate(self.layers):
+            kc, vc = self.kv[li]
+            qkv = ops.rope_reshape_and_cache(self.positions, mm(x, amax, lw["qkv"]), nh, nkv, D, self.cos_sin_cache, kc, vc,
+                                             self.slot_mapping, self.kv_dtype, self.kv_scale)
+            a = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li)
+            h = mm(a.view(-1, nh * D), None, lw["o"])
+            amax = ops.fused_add_rms_norm_absmax(h, resid, lw["ln2"], 1e-5)
+            gu = mm(h, amax, lw["gate_up"])
+            act = torch.empty(gu.shape[0], cfg["inter"], dtype=gu.dtype, device=gu.device)
+            amax = ops.silu_and_mul_absmax(act, gu)
+            x = mm(act, amax, lw["down"])
+            nxt = self.layers[li + 1]["ln1"] if li + 1 < self.n_layers else self.final_ln
+            amax = ops.fused_add_rms_norm_absmax(x, resid, nxt, 1e-5)
+        logits = torch.matmul(x, self.lm_head.t())
+        self.next_tokens.copy_(logits.argmax(-1))
+        return self.next_tokens
+
     def step(self):
         """Same op sequence as the reference's LlamaDecoderLayer (vllm/model_executor/models/llama.py:154-230):
         fused_add_rms_norm -> qkv -> rotary_embedding (in place) -> reshape_and_cache -> paged_attention -> o_proj ->
         fused_add_rms_norm -> gate_up -> silu_and_mul -> down."""
         if self.fuse:
-            return self.step_fused()
+            return self.step_fused_fp8() if self.variant == "fp8" else self.step_fused()
         cfg, ops = self.cfg, self.ops
         nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
         h = self.embed[self.tokens]
@@ -544,7 +577,7 @@ def main():
     model = Llama3Decode(ops, cfg, args.batch, args.ctx, args.layers, dev, variant=args.config, all_reduce=all_reduce,
                          all_gather=all_gather, awq_marlin=not args.awq_op, attn=args.attn)
 
-    model.fuse = args.config == "int4" and not args.no_fuse
+    model.fuse = args.config in ("int4", "fp8") and not args.no_fuse and (args.config == "int4" or tp == 0)
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()
     graph = None

@@ -243,6 +243,12 @@ int nmx_gptq_shuffle(int32_t* q_weight, int32_t* tmp, const int32_t* q_perm, int
  * (per-workgroup maxima), ignored otherwise. */
 int nmx_scaled_fp8_quant(void* out, const void* input, float* scale, float* scratch, int64_t scratch_bytes,
                          int64_t numel, int dtype, int dynamic, nmx_stream_t stream);
+/* dynamic_scaled_fp8_quant from per-workgroup maxima the producer of `input` left behind (round 2): partials[0 .. nparts)
+ * = max|input| over disjoint pieces covering the tensor (nmx_rms_norm_absmax & co. write one per token). One launch;
+ * *scale and the codes are bit-identical to nmx_scaled_fp8_quant(dynamic). Optional fusion of Fp8LinearMethod.apply's
+ * `ops.scaled_fp8_quant(x, None)` (vllm/model_executor/layers/quantization/fp8.py:340-359) with the op before it. */
+int nmx_scaled_fp8_quant_partials(void* out, const void* input, float* scale, const float* partials, int nparts,
+                                  int64_t numel, int dtype, nmx_stream_t stream);
 /* static_scaled_int8_quant / dynamic_scaled_int8_quant (csrc/quantization/compressed_tensors/int8_quant_kernels.cu:75-115).
  * static: int8(rn(x / scales[0])); dynamic: per token scales[t] = max|x_t| / 127, int8(rn(x * 127 / max|x_t|)). */
 int nmx_scaled_int8_quant(void* out, const void* input, float* scales, int num_tokens, int hidden_size, int dtype,
@@ -282,6 +288,15 @@ enum { NMX_ACT_SILU = 0, NMX_ACT_GELU = 1, NMX_ACT_GELU_TANH = 2, NMX_ACT_GELU_N
        NMX_ACT_GELU_QUICK = 5 };
 /* silu_and_mul / gelu_and_mul / gelu_tanh_and_mul: out [T, d] = ACT(in[T, :d]) * in[T, d:] */
 int nmx_act_and_mul(void* out, const void* input, int num_tokens, int d, int act, int dtype, nmx_stream_t stream);
+/* rms_norm / fused_add_rms_norm / act_and_mul that ALSO leave absmax[t] = max |out[t, :]| (of the rounded outputs) for
+ * nmx_scaled_fp8_quant_partials: the layer norm / activation in front of an fp8 linear layer
+ * (csrc/layernorm_kernels.cu:22-46,258-291, csrc/activation_kernels.cu:12-24; outputs identical to the plain entries). */
+int nmx_rms_norm_absmax(void* out, const void* input, const void* weight, float epsilon, int num_tokens, int hidden_size,
+                        int dtype, float* absmax, nmx_stream_t stream);
+int nmx_fused_add_rms_norm_absmax(void* input, void* residual, const void* weight, float epsilon, int num_tokens,
+                                  int hidden_size, int dtype, float* absmax, nmx_stream_t stream);
+int nmx_act_and_mul_absmax(void* out, const void* input, int num_tokens, int d, int act, int dtype, float* absmax,
+                           nmx_stream_t stream);
 /* gelu_new / gelu_fast / gelu_quick: out [T, d] = ACT(in [T, d]) */
 int nmx_activation(void* out, const void* input, int num_tokens, int d, int act, int dtype, nmx_stream_t stream);
 

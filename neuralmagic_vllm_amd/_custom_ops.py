@@ -851,6 +851,54 @@ def scaled_fp8_quant(
     return output, scale
 
 
+def rms_norm_absmax(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> torch.Tensor:
+    """rms_norm that also returns absmax[t] = max |out[t, :]| (float32 [T]) for scaled_fp8_quant_partials."""
+    _dev(input)
+    hidden = input.shape[-1]
+    T = input.numel() // hidden
+    amax = torch.empty(T, dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().nmx_rms_norm_absmax(_p(out), _p(input), _p(weight), c_f(epsilon), c_int(T), c_int(hidden),
+                                              c_int(_dt(input)), _p(amax), _stream(input)))
+    return amax
+
+
+def fused_add_rms_norm_absmax(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, epsilon: float) -> torch.Tensor:
+    """fused_add_rms_norm (in place on input / residual) that also returns the per-token |max| of the normed output."""
+    _dev(input)
+    hidden = input.shape[-1]
+    T = input.numel() // hidden
+    amax = torch.empty(T, dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().nmx_fused_add_rms_norm_absmax(_p(input), _p(residual), _p(weight), c_f(epsilon), c_int(T),
+                                                        c_int(hidden), c_int(_dt(input)), _p(amax), _stream(input)))
+    return amax
+
+
+def silu_and_mul_absmax(out: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """silu_and_mul that also returns the per-token |max| of its output."""
+    _dev(x)
+    d = x.shape[-1] // 2
+    T = x.numel() // x.shape[-1]
+    amax = torch.empty(T, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().nmx_act_and_mul_absmax(_p(out), _p(x), c_int(T), c_int(d), c_int(0), c_int(_dt(x)), _p(amax),
+                                                 _stream(x)))
+    return amax
+
+
+def scaled_fp8_quant_partials(input: torch.Tensor, partials: torch.Tensor, out: Optional[torch.Tensor] = None
+                              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dynamic per-tensor fp8 quantisation in ONE launch, from the maxima the producer of `input` left (rms_norm_absmax,
+    fused_add_rms_norm_absmax, silu_and_mul_absmax). Same (codes, scale) as scaled_fp8_quant(input), bit for bit."""
+    _dev(input)
+    if partials.dtype != torch.float32 or not partials.is_contiguous():
+        raise RuntimeError("scaled_fp8_quant_partials: partials must be a contiguous float32 tensor")
+    x = input if input.is_contiguous() else input.contiguous()
+    output = out if out is not None else torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    scale = torch.empty(1, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nmx_scaled_fp8_quant_partials(_p(output), _p(x), _p(scale), _p(partials), c_int(partials.numel()),
+                                                        c_i64(x.numel()), c_int(_dt(x)), _stream(x)))
+    return output, scale
+
+
 def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                       dynamic_scale_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Same contract as vllm/_custom_ops.py:324-350. out / dynamic_scale_out: the `Tensor!` operands of

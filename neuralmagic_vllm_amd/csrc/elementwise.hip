@@ -22,6 +22,22 @@ __device__ __forceinline__ float block_sum(float v, float* smem) {
   return smem[16];
 }
 
+// max over the workgroup, written by thread 0 (dynamic fp8 quantisation: the producer of an activation leaves one |max|
+// per workgroup for nmx_scaled_fp8_quant_partials instead of a separate absmax launch re-reading the tensor)
+__device__ __forceinline__ void block_max_store(float v, float* smem, float* dst) {
+  v = wave_reduce_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();  // smem may still be read by block_sum's callers
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t = fmaxf(t, smem[w]);
+    *dst = t;
+  }
+}
+
 template <typename T> __device__ __forceinline__ T rnd_mul(T a, T b) {  // scalar_t * scalar_t -> scalar_t
   return Scalar<T>::from_f32(Scalar<T>::to_f32(a) * Scalar<T>::to_f32(b));
 }
@@ -30,7 +46,7 @@ template <typename T> __device__ __forceinline__ T rnd_mul(T a, T b) {  // scala
 // fused_add_rms_norm (:258-291): z = input + residual (scalar_t); residual = z; input = scalar_t(z * s) * weight
 template <typename T, bool FUSED_ADD>
 __global__ void rms_norm_kernel(T* __restrict__ out, T* __restrict__ input, T* __restrict__ residual,
-                                const T* __restrict__ weight, float eps, int hidden) {
+                                const T* __restrict__ weight, float eps, int hidden, float* __restrict__ absmax) {
   __shared__ float smem[17];
   const int64_t row = (int64_t)blockIdx.x * hidden;
   float var = 0.f;
@@ -45,17 +61,21 @@ __global__ void rms_norm_kernel(T* __restrict__ out, T* __restrict__ input, T* _
   }
   var = block_sum(var, smem);
   const float s = rsqrtf(var / (float)hidden + eps);
+  float amax = 0.f;
   for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
     const T x = FUSED_ADD ? residual[row + i] : input[row + i];
     const T n = Scalar<T>::from_f32(Scalar<T>::to_f32(x) * s);
-    out[row + i] = rnd_mul<T>(n, weight[i]);
+    const T o = rnd_mul<T>(n, weight[i]);
+    out[row + i] = o;
+    amax = fmaxf(amax, fabsf(Scalar<T>::to_f32(o)));
   }
+  if (absmax != nullptr) block_max_store(amax, smem, absmax + blockIdx.x);
 }
 
 // 16-B vectorised fp16 / bf16 variant (hidden % 8 == 0, 16-B aligned rows), one pass over registers
 template <typename T, bool FUSED_ADD, int VPT>  // VPT = 16-B vectors per thread
 __global__ void rms_norm_vec_kernel(T* __restrict__ out, T* __restrict__ input, T* __restrict__ residual,
-                                    const T* __restrict__ weight, float eps, int hidden) {
+                                    const T* __restrict__ weight, float eps, int hidden, float* __restrict__ absmax) {
   __shared__ float smem[17];
   const int64_t row = (int64_t)blockIdx.x * hidden;
   const int nvec = hidden / 8;
@@ -90,16 +110,21 @@ __global__ void rms_norm_vec_kernel(T* __restrict__ out, T* __restrict__ input, 
   }
   var = block_sum(var, smem);
   const float s = rsqrtf(var / (float)hidden + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int v = threadIdx.x + k * blockDim.x;
     if (v < nvec) {
       V o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * s), w[k].e[j]);
+      for (int j = 0; j < 8; ++j) {
+        o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * s), w[k].e[j]);
+        amax = fmaxf(amax, fabsf(Scalar<T>::to_f32(o.e[j])));
+      }
       *reinterpret_cast<u32x4*>(out + row + v * 8) = o.u;
     }
   }
+  if (absmax != nullptr) block_max_store(amax, smem, absmax + blockIdx.x);
 }
 
 // rotary embedding (pos_encoding_kernels.cu:10-96): in place on query / key, NeoX or GPT-J pairing.
@@ -197,9 +222,12 @@ __device__ __forceinline__ T act_fn(T xv) {
 
 // act_and_mul (activation_kernels.cu:12-24): out[t, i] = ACT(in[t, i]) * in[t, d + i]
 template <typename T, int ACT>
-__global__ void act_and_mul_kernel(T* __restrict__ out, const T* __restrict__ in, int d) {
+__global__ void act_and_mul_kernel(T* __restrict__ out, const T* __restrict__ in, int d, float* __restrict__ absmax) {
+  __shared__ float smem[17];
   const int64_t tok = blockIdx.x;
   const T* x = in + tok * 2 * d;
+  float amax = 0.f;
+  bool done = false;
   if constexpr (sizeof(T) == 2) {
     if ((d & 7) == 0) {
       union V { u32x4 u; T e[8]; };
@@ -208,13 +236,23 @@ __global__ void act_and_mul_kernel(T* __restrict__ out, const T* __restrict__ in
         a.u = *reinterpret_cast<const u32x4*>(x + v * 8);
         b.u = *reinterpret_cast<const u32x4*>(x + d + v * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(act_fn<T, ACT>(a.e[j]), b.e[j]);
+        for (int j = 0; j < 8; ++j) {
+          o.e[j] = rnd_mul<T>(act_fn<T, ACT>(a.e[j]), b.e[j]);
+          amax = fmaxf(amax, fabsf(Scalar<T>::to_f32(o.e[j])));
+        }
         *reinterpret_cast<u32x4*>(out + tok * d + v * 8) = o.u;
       }
-      return;
+      done = true;
     }
   }
-  for (int i = threadIdx.x; i < d; i += blockDim.x) out[tok * d + i] = rnd_mul<T>(act_fn<T, ACT>(x[i]), x[d + i]);
+  if (!done) {
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+      const T o = rnd_mul<T>(act_fn<T, ACT>(x[i]), x[d + i]);
+      out[tok * d + i] = o;
+      amax = fmaxf(amax, fabsf(Scalar<T>::to_f32(o)));
+    }
+  }
+  if (absmax != nullptr) block_max_store(amax, smem, absmax + blockIdx.x);
 }
 
 template <typename T, int ACT>
@@ -225,7 +263,7 @@ __global__ void activation_kernel(T* __restrict__ out, const T* __restrict__ in,
 
 template <typename T>
 int launch_rms(void* out, void* input, void* residual, const void* weight, float eps, int num_tokens, int hidden,
-               bool fused, hipStream_t stream) {
+               bool fused, hipStream_t stream, float* absmax = nullptr) {
   const bool vec = sizeof(T) == 2 && hidden % 8 == 0 &&
                    (((uintptr_t)out | (uintptr_t)input | (uintptr_t)weight | (uintptr_t)residual) % 16 == 0) &&
                    hidden / 8 <= 1024 * 2;
@@ -234,25 +272,25 @@ int launch_rms(void* out, void* input, void* residual, const void* weight, float
     int threads = std::min(1024, ((nvec + 63) / 64) * 64);
     if (nvec > 256 && nvec <= 2048) threads = std::min(1024, ((nvec / 2 + 63) / 64) * 64);  // 2 vectors per thread
     const int vpt = (nvec + threads - 1) / threads;
-#define NMX_RMS(F, V) rms_norm_vec_kernel<T, F, V><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden)
+#define NMX_RMS(F, V) rms_norm_vec_kernel<T, F, V><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden, absmax)
     if (fused) { if (vpt == 1) NMX_RMS(true, 1); else NMX_RMS(true, 2); }
     else { if (vpt == 1) NMX_RMS(false, 1); else NMX_RMS(false, 2); }
 #undef NMX_RMS
   } else {
     const int threads = std::min(1024, ((hidden + 63) / 64) * 64);
-    if (fused) rms_norm_kernel<T, true><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden);
-    else rms_norm_kernel<T, false><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden);
+    if (fused) rms_norm_kernel<T, true><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden, absmax);
+    else rms_norm_kernel<T, false><<<num_tokens, threads, 0, stream>>>((T*)out, (T*)input, (T*)residual, (const T*)weight, eps, hidden, absmax);
   }
   NMX_LAUNCH_CHECK();
   return NMX_OK;
 }
 
 template <typename T>
-int launch_act(void* out, const void* in, int num_tokens, int d, int act, bool gated, hipStream_t stream) {
+int launch_act(void* out, const void* in, int num_tokens, int d, int act, bool gated, hipStream_t stream, float* absmax = nullptr) {
   const int work = (gated && sizeof(T) == 2 && d % 8 == 0) ? d / 8 : d;
   const int threads = std::min(1024, std::max(64, ((work + 63) / 64) * 64));
 #define NMX_ACT(A)                                                                                      \
-  if (gated) act_and_mul_kernel<T, A><<<num_tokens, threads, 0, stream>>>((T*)out, (const T*)in, d);    \
+  if (gated) act_and_mul_kernel<T, A><<<num_tokens, threads, 0, stream>>>((T*)out, (const T*)in, d, absmax);    \
   else activation_kernel<T, A><<<num_tokens, threads, 0, stream>>>((T*)out, (const T*)in, d)
   switch (act) {
     case ACT_SILU: NMX_ACT(ACT_SILU); break;
@@ -486,6 +524,29 @@ extern "C" int nmx_rotary_embedding(const int64_t* positions, void* query, void*
             "rot_dim = %d must be even and <= head_size = %d", rot_dim, head_size);
   NMX_DISPATCH_DT(dtype, launch_rotary<T>(positions, query, key, cos_sin_cache, cos_sin_cache_offsets, rot_dim, query_stride,
                                           key_stride, num_tokens, num_heads, num_kv_heads, head_size, is_neox, (hipStream_t)stream));
+}
+
+// Producer-side absmax (dynamic fp8 activation quantisation, fp8.py:340-359): the same kernels, plus absmax[t] = max |out[t, :]|
+// of the rounded outputs; nmx_scaled_fp8_quant_partials turns the num_tokens maxima into the tensor scale.
+extern "C" int nmx_rms_norm_absmax(void* out, const void* input, const void* weight, float epsilon, int num_tokens,
+                                   int hidden_size, int dtype, float* absmax, nmx_stream_t stream) {
+  if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK(hidden_size > 0 && absmax != nullptr, NMX_ERR_INVALID_ARG, "hidden_size must be > 0 and absmax non-null");
+  NMX_DISPATCH_DT(dtype, launch_rms<T>(out, const_cast<void*>(input), nullptr, weight, epsilon, num_tokens, hidden_size, false, (hipStream_t)stream, absmax));
+}
+
+extern "C" int nmx_fused_add_rms_norm_absmax(void* input, void* residual, const void* weight, float epsilon, int num_tokens,
+                                             int hidden_size, int dtype, float* absmax, nmx_stream_t stream) {
+  if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK(hidden_size > 0 && absmax != nullptr, NMX_ERR_INVALID_ARG, "hidden_size must be > 0 and absmax non-null");
+  NMX_DISPATCH_DT(dtype, launch_rms<T>(input, input, residual, weight, epsilon, num_tokens, hidden_size, true, (hipStream_t)stream, absmax));
+}
+
+extern "C" int nmx_act_and_mul_absmax(void* out, const void* input, int num_tokens, int d, int act, int dtype, float* absmax,
+                                      nmx_stream_t stream) {
+  if (num_tokens == 0 || d == 0) return NMX_OK;
+  NMX_CHECK(absmax != nullptr, NMX_ERR_INVALID_ARG, "absmax must be non-null");
+  NMX_DISPATCH_DT(dtype, launch_act<T>(out, input, num_tokens, d, act, true, (hipStream_t)stream, absmax));
 }
 
 extern "C" int nmx_act_and_mul(void* out, const void* input, int num_tokens, int d, int act, int dtype,

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(1024) void fp8_quant_kernel(uint8_t* __restrict__ o
                                                          int64_t n8) {
   float sc;
   if constexpr (DYNAMIC) {
-    float m = (int)(threadIdx.x & 63) < nparts ? partial[threadIdx.x & 63] : 0.f;  // nparts <= 64: one per lane
+    float m = 0.f;  // <= 64 partials from fp8_absmax_kernel, or one per token from a producer kernel (L2-resident)
+    for (int i = threadIdx.x & 63; i < nparts; i += 64) m = fmaxf(m, partial[i]);
     m = wave_reduce_max(m);
     sc = m / 448.0f;
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale = sc;
@@ -831,6 +832,29 @@ extern "C" int nmx_scaled_fp8_quant(void* out, const void* input, float* scale, 
     default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "scaled_fp8_quant: unsupported dtype %d", dtype);
   }
 #undef NMX_FP8Q
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
+// Dynamic per-tensor fp8 quantisation from partial maxima that the PRODUCER of `input` left behind
+// (nmx_rms_norm_absmax / nmx_fused_add_rms_norm_absmax / nmx_act_and_mul_absmax: one |max| per token): one launch
+// instead of absmax + quantise, the same scale and codes bit for bit (the maximum does not depend on how it is grouped).
+extern "C" int nmx_scaled_fp8_quant_partials(void* out, const void* input, float* scale, const float* partials, int nparts,
+                                             int64_t numel, int dtype, nmx_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (numel == 0) return NMX_OK;
+  NMX_CHECK(partials != nullptr && nparts > 0, NMX_ERR_INVALID_ARG, "scaled_fp8_quant_partials: needs the producer's maxima");
+  const int esz = dtype == NMX_F32 ? 4 : 2;
+  const bool vec = (uintptr_t)input % (8 * esz) == 0 && (uintptr_t)out % 8 == 0;
+  const int64_t n8 = vec ? numel / 8 : 0;
+  const int threads = 1024;
+  const int qblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(vec ? numel / 8 : numel, threads), 1024));
+  switch (dtype) {
+    case NMX_F32: fp8_quant_kernel<float, true><<<qblocks, threads, 0, stream>>>((uint8_t*)out, (const float*)input, scale, partials, nparts, numel, n8); break;
+    case NMX_F16: fp8_quant_kernel<f16, true><<<qblocks, threads, 0, stream>>>((uint8_t*)out, (const f16*)input, scale, partials, nparts, numel, n8); break;
+    case NMX_BF16: fp8_quant_kernel<bf16, true><<<qblocks, threads, 0, stream>>>((uint8_t*)out, (const bf16*)input, scale, partials, nparts, numel, n8); break;
+    default: NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "scaled_fp8_quant_partials: unsupported dtype %d", dtype);
+  }
   NMX_LAUNCH_CHECK();
   return NMX_OK;
 }

@@ -133,3 +133,40 @@ def test_deferred_materialize_matches_plain(ops):
     plain, g = _gemm_pair(ops, a, q, s, K, N)
     assert g.splits > 1
     assert torch.equal(_bits(g.materialize()), _bits(plain))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,hidden", [(1, 4096), (64, 4096), (7, 1000), (256, 14336)])
+def test_absmax_producers_and_quant_from_partials(ops, dtype, T, hidden):
+    """rms_norm / fused_add_rms_norm / silu_and_mul with the per-token |max| side output (the producers of an fp8 linear
+    layer's input): outputs identical to the plain ops, maxima exact, and scaled_fp8_quant_partials returns the codes and the
+    scale of dynamic scaled_fp8_quant bit for bit."""
+    seed_all(T + hidden)
+    x = (torch.randn(T, hidden, dtype=dtype, device=DEV) * 3)
+    w = torch.randn(hidden, dtype=dtype, device=DEV)
+    out_a, out_b = torch.empty_like(x), torch.empty_like(x)
+    amax = ops.rms_norm_absmax(out_a, x, w, 1e-5)
+    ops.rms_norm(out_b, x, w, 1e-5)
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(amax, out_b.float().abs().amax(dim=1))
+    q_a, s_a = ops.scaled_fp8_quant_partials(out_a, amax)
+    q_b, s_b = ops.scaled_fp8_quant(out_b)
+    assert torch.equal(s_a, s_b) and torch.equal(q_a.view(torch.uint8), q_b.view(torch.uint8))
+    # fused add
+    res_a = torch.randn(T, hidden, dtype=dtype, device=DEV)
+    res_b, xa, xb = res_a.clone(), x.clone(), x.clone()
+    amax = ops.fused_add_rms_norm_absmax(xa, res_a, w, 1e-5)
+    ops.fused_add_rms_norm(xb, res_b, w, 1e-5)
+    assert torch.equal(xa, xb) and torch.equal(res_a, res_b)
+    assert torch.equal(amax, xb.float().abs().amax(dim=1))
+    # gated activation
+    if hidden % 2 == 0:
+        act_a = torch.empty(T, hidden // 2, dtype=dtype, device=DEV)
+        act_b = torch.empty_like(act_a)
+        amax = ops.silu_and_mul_absmax(act_a, x)
+        ops.silu_and_mul(act_b, x)
+        assert torch.equal(act_a, act_b)
+        assert torch.equal(amax, act_b.float().abs().amax(dim=1))
+        q_a, s_a = ops.scaled_fp8_quant_partials(act_a, amax)
+        q_b, s_b = ops.scaled_fp8_quant(act_b)
+        assert torch.equal(s_a, s_b) and torch.equal(q_a.view(torch.uint8), q_b.view(torch.uint8))
