@@ -184,6 +184,10 @@ int nmx_awq_marlin_repack(const int32_t* qweight, const int32_t* qzeros, const v
                           void* out_scales, void* out_zeros, int size_k, int size_n, int num_groups, nmx_stream_t stream);
 int nmx_awq_marlin_gemm(const void* a, const int32_t* q, const void* scales, const void* zeros, void* c, void* scratch,
                         int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_groups, nmx_stream_t stream);
+/* the same with the split-K reduce left to the consumer op (see nmx_gptq_marlin_gemm_deferred) */
+int nmx_awq_marlin_gemm_deferred(const void* a, const int32_t* q, const void* scales, const void* zeros, void* c,
+                                 void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_groups,
+                                 int* splits_out, nmx_stream_t stream);
 
 /* marlin_gemm (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136): int4, fp16, groups of 128 or
  * channel-wise, weights Marlin-packed in the checkpoint. */

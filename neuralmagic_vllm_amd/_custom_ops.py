@@ -735,6 +735,28 @@ def awq_marlin_gemm(a: torch.Tensor, marlin_q: torch.Tensor, marlin_scales: torc
     return c
 
 
+def awq_marlin_gemm_deferred(a: torch.Tensor, marlin_q: torch.Tensor, marlin_scales: torch.Tensor, marlin_zeros: torch.Tensor,
+                             size_m: int, size_n: int, size_k: int) -> DeferredGemm:
+    """awq_marlin_gemm whose split-K partial sums are left for the consumer op (fused_add_rms_norm_splitk, silu_and_mul_splitk,
+    rope_reshape_and_cache), like gptq_marlin_gemm_deferred."""
+    _dev(a)
+    if a.dtype != torch.float16 or a.dim() != 2 or a.shape[0] != size_m or a.shape[1] != size_k or not a.is_contiguous():
+        raise RuntimeError("awq_marlin_gemm: a must be a contiguous fp16 [size_m, size_k] tensor")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return DeferredGemm(c, None, 1)
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    splits = c_int(1)
+    _lib.check(_lib.lib().nmx_awq_marlin_gemm_deferred(_p(a), _p(marlin_q), _p(marlin_scales), _p(marlin_zeros), _p(c),
+                                                       _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n),
+                                                       c_int(size_k), c_int(marlin_scales.shape[0]), ctypes.byref(splits),
+                                                       _stream(a)))
+    if splits.value > 1:
+        partial = scratch[:splits.value * size_m * size_n * 4].view(torch.float32).view(splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, splits.value)
+    return DeferredGemm(c, None, 1)
+
+
 def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor, b_gptq_scales: torch.Tensor,
               b_g_idx: torch.Tensor, use_exllama: bool, bit: int) -> torch.Tensor:
     # csrc/quantization/gptq/q_gemm.cu:1823-1848

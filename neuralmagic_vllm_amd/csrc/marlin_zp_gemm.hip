@@ -78,10 +78,10 @@ extern "C" int nmx_awq_marlin_supported(int size_n, int size_k, int num_groups) 
   return (g % 128 == 0 && size_k % 128 == 0 && size_n % 64 == 0 && (int64_t)size_k * size_n < (1ll << 31)) ? 1 : 0;
 }
 
-extern "C" int nmx_awq_marlin_gemm(const void* a, const int32_t* q, const void* scales, const void* zeros, void* c,
-                                   void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k,
-                                   int num_groups, nmx_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int awq_marlin_common(const void* a, const int32_t* q, const void* scales, const void* zeros, void* c, void* scratch,
+                             int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_groups, bool defer,
+                             int* splits_out, hipStream_t stream) {
+  if (splits_out != nullptr) *splits_out = 1;
   NMX_CHECK(nmx_awq_marlin_supported(size_n, size_k, num_groups), NMX_ERR_UNSUPPORTED,
             "awq_marlin_gemm: group size must be a multiple of 128, size_n of 64 (use awq_gemm)");
   NMX_CHECK(((uintptr_t)a % 16 == 0) && ((uintptr_t)q % 16 == 0) && ((uintptr_t)scales % 16 == 0) && ((uintptr_t)zeros % 16 == 0) &&
@@ -91,7 +91,7 @@ extern "C" int nmx_awq_marlin_gemm(const void* a, const int32_t* q, const void* 
   GemmParams p;
   p.a = a; p.b = q; p.meta = nullptr; p.scales = scales; p.zeros = zeros; p.g_idx = nullptr; p.perm = nullptr; p.c = c;
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.group_size = size_k / num_groups;
-  p.slow_act_order = 0; p.defer_reduce = 0;
+  p.slow_act_order = 0; p.defer_reduce = defer ? 1 : 0;
   GemmCfg cfg = pick_cfg(size_m, size_n, size_k);
   // the 64-row x 128-column tiles need more registers than two waves per SIMD leave with the zero points on top (hipcc
   // spills, and a spill of a register an in-flight load is writing is not safe): 256-column tiles instead
@@ -104,10 +104,28 @@ extern "C" int nmx_awq_marlin_gemm(const void* a, const int32_t* q, const void* 
   p.partial = reinterpret_cast<float*>(scratch);
   const int rc = launch_mode<f16, W_INT4, 1, false, true>(p, cfg, stream);
   if (rc != NMX_OK) return rc;
-  if (p.k_splits > 1) {
+  if (splits_out != nullptr) *splits_out = p.k_splits;
+  if (p.k_splits > 1 && !defer) {
     const int64_t mn4 = (int64_t)size_m * size_n / 4;
     splitk_reduce_kernel<f16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<f16*>(c), p.partial, mn4, p.k_splits);
     NMX_LAUNCH_CHECK();
   }
   return NMX_OK;
+}
+
+extern "C" int nmx_awq_marlin_gemm(const void* a, const int32_t* q, const void* scales, const void* zeros, void* c,
+                                   void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k,
+                                   int num_groups, nmx_stream_t stream) {
+  return awq_marlin_common(a, q, scales, zeros, c, scratch, scratch_bytes, size_m, size_n, size_k, num_groups, false, nullptr,
+                           (hipStream_t)stream);
+}
+
+// The same GEMM with the split-K reduce left to the consumer (nmx_fused_add_rms_norm_splitk / nmx_silu_and_mul_splitk /
+// nmx_rope_reshape_and_cache): *splits_out slabs of fp32 [M, N] are in `scratch`, c is written only when *splits_out == 1.
+extern "C" int nmx_awq_marlin_gemm_deferred(const void* a, const int32_t* q, const void* scales, const void* zeros, void* c,
+                                            void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k,
+                                            int num_groups, int* splits_out, nmx_stream_t stream) {
+  NMX_CHECK(splits_out != nullptr, NMX_ERR_INVALID_ARG, "awq_marlin_gemm_deferred: splits_out must be non-null");
+  return awq_marlin_common(a, q, scales, zeros, c, scratch, scratch_bytes, size_m, size_n, size_k, num_groups, true, splits_out,
+                           (hipStream_t)stream);
 }

@@ -170,3 +170,26 @@ def test_absmax_producers_and_quant_from_partials(ops, dtype, T, hidden):
         q_a, s_a = ops.scaled_fp8_quant_partials(act_a, amax)
         q_b, s_b = ops.scaled_fp8_quant(act_b)
         assert torch.equal(s_a, s_b) and torch.equal(q_a.view(torch.uint8), q_b.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M", [1, 16, 64, 256])
+@pytest.mark.parametrize("K,N", [(8192, 1280), (1024, 8192), (3584, 8192)])
+def test_deferred_awq_marlin_gemm(ops, M, K, N):
+    """AWQ repacked onto the Marlin kernel (Llama-3-70B TP = 8 rank shapes): the deferred form + fused consumer is
+    bit-identical to awq_marlin_gemm + the plain op."""
+    seed_all(M + K)
+    g128 = K // 128
+    qw = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int32, device=DEV)
+    qz = torch.randint(-2**31, 2**31 - 1, (g128, N // 8), dtype=torch.int32, device=DEV)
+    sc = (torch.rand(g128, N, device=DEV) * 0.004 + 0.002).to(torch.float16)
+    mq, ms, mz = ops.awq_marlin_repack(qw, qz, sc)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV)
+    plain = ops.awq_marlin_gemm(a, mq, ms, mz, M, N, K)
+    g = ops.awq_marlin_gemm_deferred(a, mq, ms, mz, M, N, K)
+    res0 = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    w = (torch.rand(N, device=DEV) + 0.5).half()
+    res_a, res_b = res0.clone(), res0.clone()
+    ops.fused_add_rms_norm(plain, res_a, w, 1e-5)
+    fused = ops.fused_add_rms_norm_splitk(g, res_b, w, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(fused), _bits(plain)) and torch.equal(_bits(res_a), _bits(res_b))
