@@ -253,6 +253,8 @@ class Llama3Decode:
 
         def gemm(x, w, name):
             K, N = self.shapes[name]
+            if self.variant == "sparse24":
+                return ops.gptq_marlin_24_gemm_deferred(x, w[0], w[1], w[2], ws, 4, x.shape[0], N, K)
             if self.variant != "int4":  # AWQ repacked onto the Marlin kernel (awq70b configs)
                 return ops.awq_marlin_gemm_deferred(x, w[0], w[1], w[2], x.shape[0], N, K)
             return ops.gptq_marlin_gemm_deferred(x, w[0], w[1], e, e, ws, 4, x.shape[0], N, K, True)
@@ -582,7 +584,7 @@ def main():
     # AWQ (hidden 8192): one workgroup per token reading 2-4 fp32 slabs of a 32-KiB row is slower than the 512-workgroup
     # reduce launch until there are >= 128 rows (measured: batch 64 7.81 vs 7.71 ms, batch 256 12.61 vs 13.28 ms)
     awq_fusable = args.config.startswith("awq70b") and not args.awq_op and args.batch >= 128
-    model.fuse = (args.config in ("int4", "fp8") or awq_fusable) and not args.no_fuse and (args.config != "fp8" or tp == 0)
+    model.fuse = (args.config in ("int4", "fp8", "sparse24") or awq_fusable) and not args.no_fuse and (args.config != "fp8" or tp == 0)
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()
     graph = None

@@ -204,6 +204,11 @@ int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scal
 int nmx_gptq_marlin_24_gemm(const void* a, const int32_t* b_q_weight, const void* b_meta, const void* b_scales,
                             void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int num_bits,
                             int size_m, int size_n, int size_k, int num_groups, int dtype, nmx_stream_t stream);
+/* the same with the split-K reduce left to the consumer op (see nmx_gptq_marlin_gemm_deferred) */
+int nmx_gptq_marlin_24_gemm_deferred(const void* a, const int32_t* b_q_weight, const void* b_meta, const void* b_scales,
+                            void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int num_bits,
+                            int size_m, int size_n, int size_k, int num_groups, int dtype, int* splits_out,
+                                     nmx_stream_t stream);
 
 /* fp8_marlin_gemm (csrc/quantization/fp8/fp8_marlin.cu:1212-1308): W8A16, weight bytes are e4m3fn, channel-wise
  * scales [1, size_n] (Marlin single-permuted). */

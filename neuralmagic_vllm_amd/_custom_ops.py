@@ -620,6 +620,29 @@ def gptq_marlin_24_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_meta: torch
     return c
 
 
+def gptq_marlin_24_gemm_deferred(a: torch.Tensor, b_q_weight: torch.Tensor, b_meta: torch.Tensor, b_scales: torch.Tensor,
+                                 workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int, size_k: int) -> DeferredGemm:
+    """gptq_marlin_24_gemm whose split-K partial sums are left for the consumer op, like gptq_marlin_gemm_deferred
+    (argument checks: the C entry's; use the plain op to get the reference's messages)."""
+    _dev(a)
+    if a.dtype != torch.float16 or a.dim() != 2 or a.shape[0] != size_m or a.shape[1] != size_k or not a.is_contiguous():
+        raise RuntimeError("gptq_marlin_24_gemm: a must be a contiguous fp16 [size_m, size_k] tensor")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return DeferredGemm(c, None, 1)
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    splits = c_int(1)
+    _lib.check(_lib.lib().nmx_gptq_marlin_24_gemm_deferred(_p(a), _p(b_q_weight), _p(b_meta), _p(b_scales), _p(c),
+                                                           c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()),
+                                                           c_int(num_bits), c_int(size_m), c_int(size_n), c_int(size_k),
+                                                           c_int(b_scales.size(0)), c_int(_dt(a)), ctypes.byref(splits),
+                                                           _stream(a)))
+    if splits.value > 1:
+        partial = scratch[:splits.value * size_m * size_n * 4].view(torch.float32).view(splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, splits.value)
+    return DeferredGemm(c, None, 1)
+
+
 def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor, workspace: torch.Tensor,
                     num_bits: int, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
     # checks mirror csrc/quantization/fp8/fp8_marlin.cu:1212-1280

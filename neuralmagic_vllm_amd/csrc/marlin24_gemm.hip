@@ -5,11 +5,10 @@
 // Algorithmic bytes per call: K*N*bits/16 (kept values) + K*N/8 (2-bit positions) + groups*N*2 + 2*M*K + 2*M*N.
 #include "marlin_kernel.h"
 
-extern "C" int nmx_gptq_marlin_24_gemm(const void* a, const int32_t* b_q_weight, const void* b_meta,
-                                       const void* b_scales, void* c, int64_t workspace_numel, void* scratch,
-                                       int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
-                                       int num_groups, int dtype, nmx_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int marlin24_common(const void* a, const int32_t* b_q_weight, const void* b_meta, const void* b_scales, void* c,
+                           int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int num_bits, int size_m, int size_n,
+                           int size_k, int num_groups, int dtype, bool defer, int* splits_out, hipStream_t stream) {
+  if (splits_out != nullptr) *splits_out = 1;
   // checks mirror marlin_24_cuda_kernel.cu:1024-1116
   NMX_CHECK(num_bits == 4 || num_bits == 8, NMX_ERR_INVALID_ARG, "num_bits must be 4 or 8. Got = %d", num_bits);
   NMX_CHECK(dtype == NMX_F16, NMX_ERR_UNSUPPORTED, "gptq_marlin_24_gemm only supports float16 activations");
@@ -33,7 +32,27 @@ extern "C" int nmx_gptq_marlin_24_gemm(const void* a, const int32_t* b_q_weight,
   GemmParams p;
   p.a = a; p.b = b_q_weight; p.meta = b_meta; p.zeros = nullptr; p.scales = b_scales; p.g_idx = nullptr; p.perm = nullptr; p.c = c;
   p.partial = nullptr; p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.group_size = group_size;
-  p.k_splits = 1; p.slow_act_order = 0; p.defer_reduce = 0;
-  if (num_bits == 4) return launch_skinny<f16, W_INT4, true>(p, scratch, scratch_bytes, stream);
-  return launch_skinny<f16, W_INT8, true>(p, scratch, scratch_bytes, stream);
+  p.k_splits = 1; p.slow_act_order = 0; p.defer_reduce = defer ? 1 : 0;
+  const int rc = num_bits == 4 ? launch_skinny<f16, W_INT4, true>(p, scratch, scratch_bytes, stream)
+                               : launch_skinny<f16, W_INT8, true>(p, scratch, scratch_bytes, stream);
+  if (rc == NMX_OK && splits_out != nullptr) *splits_out = p.k_splits;
+  return rc;
+}
+
+extern "C" int nmx_gptq_marlin_24_gemm(const void* a, const int32_t* b_q_weight, const void* b_meta,
+                                       const void* b_scales, void* c, int64_t workspace_numel, void* scratch,
+                                       int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
+                                       int num_groups, int dtype, nmx_stream_t stream) {
+  return marlin24_common(a, b_q_weight, b_meta, b_scales, c, workspace_numel, scratch, scratch_bytes, num_bits, size_m, size_n,
+                         size_k, num_groups, dtype, false, nullptr, (hipStream_t)stream);
+}
+
+// The same GEMM with the split-K reduce left to the consumer op (see nmx_gptq_marlin_gemm_deferred).
+extern "C" int nmx_gptq_marlin_24_gemm_deferred(const void* a, const int32_t* b_q_weight, const void* b_meta,
+                                                const void* b_scales, void* c, int64_t workspace_numel, void* scratch,
+                                                int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
+                                                int num_groups, int dtype, int* splits_out, nmx_stream_t stream) {
+  NMX_CHECK(splits_out != nullptr, NMX_ERR_INVALID_ARG, "gptq_marlin_24_gemm_deferred: splits_out must be non-null");
+  return marlin24_common(a, b_q_weight, b_meta, b_scales, c, workspace_numel, scratch, scratch_bytes, num_bits, size_m, size_n,
+                         size_k, num_groups, dtype, true, splits_out, (hipStream_t)stream);
 }

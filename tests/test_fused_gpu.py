@@ -193,3 +193,25 @@ def test_deferred_awq_marlin_gemm(ops, M, K, N):
     fused = ops.fused_add_rms_norm_splitk(g, res_b, w, 1e-5)
     torch.cuda.synchronize()
     assert torch.equal(_bits(fused), _bits(plain)) and torch.equal(_bits(res_a), _bits(res_b))
+
+
+@pytest.mark.parametrize("M", [1, 16, 64, 256])
+def test_deferred_marlin_24_gemm(ops, M):
+    """2:4-sparse Marlin GEMM: deferred split-K + fused consumer is bit-identical to the plain sequence."""
+    from oracle import packing
+    K, N = 4096, 4096
+    seed_all(M)
+    w = torch.randn(K, N, dtype=torch.float16)
+    _, q24, meta, s24 = packing.marlin_24_quantize(w, 4, 128)
+    q24, meta, s24 = q24.to(DEV), meta.to(DEV), s24.to(DEV)
+    ws = torch.zeros(N // 128 * 64, dtype=torch.int32, device=DEV)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV)
+    plain = ops.gptq_marlin_24_gemm(a, q24, meta, s24, ws, 4, M, N, K)
+    g = ops.gptq_marlin_24_gemm_deferred(a, q24, meta, s24, ws, 4, M, N, K)
+    res0 = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    wn = (torch.rand(N, device=DEV) + 0.5).half()
+    res_a, res_b = res0.clone(), res0.clone()
+    ops.fused_add_rms_norm(plain, res_a, wn, 1e-5)
+    fused = ops.fused_add_rms_norm_splitk(g, res_b, wn, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(fused), _bits(plain)) and torch.equal(_bits(res_a), _bits(res_b))
