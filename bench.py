@@ -712,7 +712,7 @@ def main():
             result["allreduce"] = ar_stats
         if args.sweep and args.config == "int4":
             result["sweep"] = sweep(ops, cfg, dev)
-        if not args.no_cpu_baseline and args.config == "int4":  # the CPU port times the headline workload only
+        if not args.no_cpu_baseline and args.config == "int4" and world == 1:  # headline workload, single-GPU run only
             result["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.ctx)
         print(json.dumps(result), flush=True)
     if dist is not None:
