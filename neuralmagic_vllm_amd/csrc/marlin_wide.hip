@@ -580,6 +580,14 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
     c.wm = env.wm; c.wn = env.wn; c.splits = env.splits; c.mt = (M <= 64 || kind == W_INT4) ? env.mt : 8;
   } else if (M <= 64) {
     c.wm = 1; c.wn = 2; c.splits = 1; c.mt = 4;
+  } else if (kind == W_INT4 && M <= 256 && K <= 4096 && N <= 8192) {
+    // small matrices (qkv, o) at 64 < M <= 256: 64-row x 128-column tiles, no K split when they alone give >= 192
+    // workgroups, else two (tools/lean_sweep.py: qkv 27.1 vs 31.0 us at M = 256, 21.6 vs 25.2 at 128; o 22.6 vs 24.2, 19.7 vs 23.5)
+    c.wm = 1; c.wn = 2; c.mt = 4;
+    c.splits = ceil_div(N, 128) * ceil_div(M, 64) >= 192 ? 1 : 2;
+  } else if (M <= 128 && K <= 8192 && ceil_div(N, 128) >= 192) {
+    // gate_up-like at 64 < M <= 128: one row block, 128-column tiles fill the chip without a split (41.0 vs 47.9 us)
+    c.wm = 1; c.wn = 2; c.splits = 1;
   } else {
     // Measured (tools/lean_sweep.py, 32-launch graph chains over distinct weights, Llama-3-8B shapes, M = 128 .. 2048;
     // gpurun_out/wide_sweep.log): 128-row x 256-column tiles with two K slices per workgroup win 13-23 % over the 64-row
