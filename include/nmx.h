@@ -327,6 +327,17 @@ int nmx_topk_softmax(float* topk_weights, int32_t* topk_ids, int32_t* token_expe
                      int num_tokens, int num_experts, int topk, nmx_stream_t stream);
 int nmx_moe_align_block_size(const int32_t* topk_ids, int num_experts, int block_size, int numel, int32_t* sorted_token_ids,
                              int max_sorted, int32_t* expert_ids, int32_t* num_tokens_post_pad, nmx_stream_t stream);
+/* Grouped fp8 GEMM over the expert-sorted (token, k) pairs - the fused_moe Triton kernel of the reference
+ * (vllm/model_executor/layers/fused_moe/fused_moe.py:20-222, invoke_fused_moe_kernel :225-292) with use_fp8:
+ * out[id, :n] = cast(dot(a[id / a_row_div, :k], w[e, :n, :k]) * [topk_weights[id]] * a_scale[0] * w_scale[e]) for every
+ * id of every block of `block_rows` entries of sorted_token_ids (entries >= num_valid are padding), e = expert_ids[block].
+ * a [a_rows, k] fp8-e4m3, w [num_experts, n, k] fp8-e4m3, out [num_valid, n] fp16 / bf16; topk_weights may be null
+ * (mul_routed_weight = False). max_blocks = entries of expert_ids; blocks past num_tokens_post_padded[0] do nothing.
+ * Nothing is read on the host: capturable. */
+int nmx_moe_scaled_mm(void* out, const void* a, const void* w, const float* a_scale, const float* w_scale,
+                      const float* topk_weights, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                      const int32_t* num_tokens_post_padded, int num_valid, int a_rows, int a_row_div, int n, int k,
+                      int num_experts, int block_rows, int max_blocks, int out_dtype, nmx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * One-shot all-reduce over the xGMI mesh for small messages. Replaces the `_C_custom_ar` ops of the reference

@@ -1,9 +1,10 @@
 """Mixture-of-experts forward on the MI355X ops — the part of vllm/model_executor/layers/fused_moe/fused_moe.py that the
 fp8 MoE method calls (fused_topk :335-368, fused_experts :402-511, fused_moe :514-585). The reference runs ONE Triton
 grouped-GEMM kernel over tokens sorted by expert; here routing is native HIP (topk_softmax, moe_align_block_size) and
-each expert's two GEMMs run on the fp8 MFMA scaled_mm kernel (`cutlass_scaled_mm`) over its slice of the sorted rows.
-First version: correct and graph-free (the per-expert row counts are read on the host once per call); a grouped kernel
-over the sorted list is the known next step. Arithmetic follows the reference: one per-tensor activation scale for the
+the fp8 path runs the two expert GEMMs as ONE grouped launch each over the sorted blocks (`moe_scaled_mm`: rows gathered
+through sorted_token_ids, results scattered to their pair id; nothing is read back on the host, so the layer is
+graph-capturable like the reference's). The unquantised path (not a target of this build) multiplies per expert with
+torch.matmul and reads the per-expert row counts on the host. Arithmetic follows the reference: one per-tensor activation scale for the
 whole batch (static, or dynamic = max over all tokens), per-expert weight scales, fp32 accumulation, routing weights
 applied to the expert outputs before the sum over k."""
 from typing import Optional, Tuple
@@ -45,8 +46,10 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     e, n2, _ = w1.shape
     topk = topk_ids.shape[1]
     dev, dt = hidden_states.device, hidden_states.dtype
-    # tokens sorted by expert (block size 1: no padding needed for per-expert slices)
     numel = m * topk
+    if use_fp8 and dt in (torch.float16, torch.bfloat16) and k % 128 == 0 and (n2 // 2) % 128 == 0:
+        return _fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, w1_scale, w2_scale, a1_scale, a2_scale)
+    # tokens sorted by expert (block size 1: no padding needed for per-expert slices)
     sorted_ids = torch.empty(numel, dtype=torch.int32, device=dev)
     expert_of_block = torch.empty(numel, dtype=torch.int32, device=dev)
     post_pad = torch.empty(1, dtype=torch.int32, device=dev)
@@ -80,6 +83,34 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     acc = torch.zeros(m, w2.shape[1], dtype=torch.float32, device=dev)
     acc.index_add_(0, src_tok, out_rows.float() * wts[:, None])
     out.copy_(acc.to(dt))
+    return out
+
+
+def _fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, w1_scale, w2_scale, a1_scale, a2_scale):
+    """fused_experts with use_fp8 (fused_moe.py:402-511): align -> quantise -> grouped GEMM (gate | up) -> silu_and_mul ->
+    quantise -> grouped GEMM with the routing weight -> sum over k. Every step is a device launch."""
+    m, k = hidden_states.shape
+    e, n2, _ = w1.shape
+    topk = topk_ids.shape[1]
+    dev, dt = hidden_states.device, hidden_states.dtype
+    numel = m * topk
+    block = 16 if numel <= 16 * e else 64  # get_default_config's BLOCK_SIZE_M: 16 for decode-size batches, else 64 (:308-332)
+    max_sorted = numel + e * (block - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
+    expert_ids = torch.empty((max_sorted + block - 1) // block, dtype=torch.int32, device=dev)
+    post_pad = torch.empty(1, dtype=torch.int32, device=dev)
+    ops.moe_align_block_size(topk_ids.contiguous(), e, block, sorted_ids, expert_ids, post_pad)
+    a_q, a1 = ops.scaled_fp8_quant(hidden_states, a1_scale)  # one scale for the whole batch (:467-472)
+    gate_up = torch.empty(numel, n2, dtype=dt, device=dev)
+    ops.moe_scaled_mm(gate_up, a_q, w1, a1, w1_scale.float().contiguous(), None, sorted_ids, expert_ids, post_pad, topk, block)
+    inter = torch.empty(numel, n2 // 2, dtype=dt, device=dev)
+    ops.silu_and_mul(inter, gate_up)
+    i_q, a2 = ops.scaled_fp8_quant(inter, a2_scale)
+    out_rows = torch.empty(numel, w2.shape[1], dtype=dt, device=dev)
+    ops.moe_scaled_mm(out_rows, i_q, w2, a2, w2_scale.float().contiguous(), topk_weights.float().contiguous(), sorted_ids,
+                      expert_ids, post_pad, 1, block)
+    out = hidden_states if inplace else torch.empty_like(hidden_states)
+    torch.sum(out_rows.view(m, topk, w2.shape[1]), dim=1, out=out)  # moe_sum (:505-510)
     return out
 
 

@@ -121,3 +121,64 @@ def test_fp8_moe_method(ops, scheme, serialized):
     # held to baseline_scaled_mm in tests/test_quant_gpu.py)
     err = float((out.float() - ref).abs().mean() / ref.abs().mean())
     assert err < 1e-1, err
+
+
+@pytest.mark.parametrize("m,e,topk,block", [(1, 8, 2, 16), (33, 8, 2, 16), (222, 8, 2, 64), (40, 64, 6, 32)])
+@pytest.mark.parametrize("n,k", [(256, 128), (1000, 512)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_moe_scaled_mm(ops, m, e, topk, block, n, k, dtype):
+    """The grouped fp8 GEMM against a per-pair torch evaluation: gather through sorted_token_ids, per-expert weight scale,
+    optional routing weight, scatter to the pair id; padding slots and blocks past num_tokens_post_padded do nothing."""
+    seed_all(m + n)
+    numel = m * topk
+    ids = torch.stack([torch.randperm(e)[:topk] for _ in range(m)]).int().to(DEV)
+    a = (torch.randn(m, k, device=DEV) * 2).to(torch.float8_e4m3fn)
+    w = (torch.randn(e, n, k, device=DEV) * 2).to(torch.float8_e4m3fn)
+    a_s = torch.tensor([0.03], device=DEV)
+    w_s = (torch.rand(e, device=DEV) * 0.05 + 0.01)
+    tw = torch.rand(m, topk, device=DEV)
+    max_sorted = numel + e * (block - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=DEV)
+    expert_ids = torch.zeros((max_sorted + block - 1) // block, dtype=torch.int32, device=DEV)
+    post = torch.empty(1, dtype=torch.int32, device=DEV)
+    ops.moe_align_block_size(ids, e, block, sorted_ids, expert_ids, post)
+    for use_tw, div in ((False, topk), (True, topk)):
+        out = torch.full((numel, n), 7.0, dtype=dtype, device=DEV)
+        ops.moe_scaled_mm(out, a, w, a_s, w_s, tw if use_tw else None, sorted_ids, expert_ids, post, div, block)
+        flat = ids.flatten().long()
+        rows = torch.arange(numel, device=DEV) // div
+        ref = torch.einsum("rk,rnk->rn", a.float()[rows], w.float()[flat])
+        if use_tw:
+            ref = ref * tw.flatten()[:, None]
+        ref = (ref * a_s * w_s[flat][:, None]).to(dtype)
+        torch.testing.assert_close(out.float(), ref.float(), rtol=1e-2, atol=2e-2)
+
+
+def test_fused_moe_fp8_is_graph_capturable(ops):
+    """The fp8 MoE layer issues device launches only: it can be captured and replayed with new inputs."""
+    from neuralmagic_vllm_amd.layers.fused_moe import fused_experts, fused_topk
+    seed_all(3)
+    e, n, k, m, topk = 8, 256, 512, 24, 2
+    w1 = (torch.randn(e, 2 * n, k, device=DEV) / 4).to(torch.float8_e4m3fn)
+    w2 = (torch.randn(e, k, n, device=DEV) / 4).to(torch.float8_e4m3fn)
+    s1 = torch.full((e, ), 0.02, device=DEV)
+    s2 = torch.full((e, ), 0.03, device=DEV)
+    x = torch.randn(m, k, dtype=torch.float16, device=DEV) / 10
+    logits = torch.randn(m, e, device=DEV)
+
+    def run():
+        tw, ids = fused_topk(x, logits, topk, True)
+        return fused_experts(x, w1, w2, tw, ids, use_fp8=True, w1_scale=s1, w2_scale=s2)
+
+    eager = run().clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = run()
+        out.zero_()
+        g.replay()
+        side.synchronize()
+    assert torch.equal(out, eager)
