@@ -408,7 +408,9 @@ __global__ void rope_cache_kernel(const int64_t* __restrict__ positions, T* __re
   const int64_t block_idx = slot / block_size, block_off = slot % block_size;
   const T* cache = cos_sin_cache + pos * head_size;
   union V { u32x4 u; T e[8]; };
-  for (int i = threadIdx.x; i < heads * vper; i += blockDim.x) {
+  // a token's heads are spread over gridDim.y workgroups of 128 threads: at decode batch sizes one workgroup per token
+  // leaves most CUs idle and every thread is a chain of dependent loads (position -> cos / sin, slot -> cache address)
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < heads * vper; i += blockDim.x * gridDim.y) {
     const int head = i / vper, ro = (i % vper) * 8;
     const int64_t base = row + (int64_t)head * head_size;
     V x, y;
@@ -617,9 +619,10 @@ extern "C" int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, c
             "rope_reshape_and_cache: operands must be 16-byte aligned");
   const int heads = num_heads + 2 * num_kv_heads;
   const int nvec = heads * (head_size / 16);
-  const int threads = std::min(512, std::max(64, ((nvec + 63) / 64) * 64));
+  const int threads = std::min(128, std::max(64, ((nvec + 63) / 64) * 64));
+  const dim3 grid(num_tokens, std::min(8, ceil_div(nvec, threads)));
   const int64_t slab = (int64_t)num_tokens * heads * head_size;
-#define NMX_RC(T, KVC) rope_cache_kernel<T, KVC><<<num_tokens, threads, 0, stream>>>(positions, (T*)qkv, partial, splits, slab, (const T*)cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads, head_size, block_size, kv_scale)
+#define NMX_RC(T, KVC) rope_cache_kernel<T, KVC><<<grid, threads, 0, stream>>>(positions, (T*)qkv, partial, splits, slab, (const T*)cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads, head_size, block_size, kv_scale)
 #define NMX_RC_T(T)                                                                       \
   switch (kv_dtype) {                                                                     \
     case NMX_KV_AUTO: NMX_RC(T, NMX_KV_AUTO); break;                                      \
