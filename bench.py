@@ -286,16 +286,18 @@ class Llama3Decode:
         return self.next_tokens
 
     def step_fused_fp8(self):
-        """fp8 config with 4 launches per layer less: the norm / activation in front of every fp8 linear layer leaves the
+        """fp8 config with fewer launches per layer: the norm / activation in front of every fp8 linear layer leaves the
         per-token |max| of its output, so the dynamic activation quantisation is one launch instead of absmax + quantise
-        (scaled_fp8_quant_partials: same scale and codes), and rotary + KV-cache write are one launch. o_proj's input
-        comes out of paged attention and keeps the two-launch quantisation."""
+        (scaled_fp8_quant_partials: same scale and codes); the fp8 GEMMs leave their K-split slabs AND their scale epilogue
+        to the consumer (cutlass_scaled_mm_deferred + the *_splitk_scaled ops: no reduce launch); rotary + KV-cache write
+        are one launch. o_proj's input comes out of paged attention and keeps the two-launch quantisation.
+        Bit-identical to step() (tests/test_fused_gpu.py)."""
         cfg, ops = self.cfg, self.ops
         nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
 
-        def mm(x, amax, w):
+        def mm(x, amax, w):  # quantise (one launch when the producer left the maxima), deferred fp8 GEMM
             qx, sx = ops.scaled_fp8_quant_partials(x, amax) if amax is not None else ops.scaled_fp8_quant(x)
-            return ops.cutlass_scaled_mm(qx, w[0], sx, w[1], torch.float16)
+            return ops.cutlass_scaled_mm_deferred(qx, w[0], sx, w[1], torch.float16)
 
         h = self.embed[self.tokens]
         resid = h
@@ -306,14 +308,12 @@ class Llama3Decode:
             qkv = ops.rope_reshape_and_cache(self.positions, mm(x, amax, lw["qkv"]), nh, nkv, D, self.cos_sin_cache, kc, vc,
                                              self.slot_mapping, self.kv_dtype, self.kv_scale)
             a = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li)
-            h = mm(a.view(-1, nh * D), None, lw["o"])
-            amax = ops.fused_add_rms_norm_absmax(h, resid, lw["ln2"], 1e-5)
+            h, amax = ops.fused_add_rms_norm_splitk(mm(a.view(-1, nh * D), None, lw["o"]), resid, lw["ln2"], 1e-5, want_absmax=True)
             gu = mm(h, amax, lw["gate_up"])
-            act = torch.empty(gu.shape[0], cfg["inter"], dtype=gu.dtype, device=gu.device)
-            amax = ops.silu_and_mul_absmax(act, gu)
-            x = mm(act, amax, lw["down"])
+            act = torch.empty(h.shape[0], cfg["inter"], dtype=h.dtype, device=h.device)
+            amax = ops.silu_and_mul_splitk(act, gu, want_absmax=True)
             nxt = self.layers[li + 1]["ln1"] if li + 1 < self.n_layers else self.final_ln
-            amax = ops.fused_add_rms_norm_absmax(x, resid, nxt, 1e-5)
+            x, amax = ops.fused_add_rms_norm_splitk(mm(act, amax, lw["down"]), resid, nxt, 1e-5, want_absmax=True)
         logits = torch.matmul(x, self.lm_head.t())
         self.next_tokens.copy_(logits.argmax(-1))
         return self.next_tokens

@@ -162,6 +162,24 @@ int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int spl
 /* silu_and_mul (csrc/activation_kernels.cu:12-30) on x = round(sum_s partial[s]); partial [splits, num_tokens, 2 d]. */
 int nmx_silu_and_mul_splitk(void* out, const float* partial, int splits, int num_tokens, int d, int dtype,
                             nmx_stream_t stream);
+/* fp8 x fp8 scaled_mm (per-tensor scales, no bias) with the K-split reduce AND the scale epilogue left to the consumer:
+ * raw fp32 slabs [*splits_out, m, n] stay in `scratch`; out is complete only when *splits_out == 1. The `_scaled` consumers
+ * below apply sa[0] * (sb[0] * sum) - the epilogue of scaled_mm_entry.cu / test_cutlass.py:35-47 - before rounding, and can
+ * leave the per-token |max| of their output for nmx_scaled_fp8_quant_partials (absmax may be null). Bit-identical to
+ * nmx_scaled_mm + the plain op. */
+int nmx_scaled_mm_deferred(void* out, const void* a, const void* b, const float* a_scale, const float* b_scale, void* scratch,
+                           int64_t scratch_bytes, int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
+                           int* splits_out, nmx_stream_t stream);
+int nmx_fused_add_rms_norm_splitk_scaled(void* input_out, const float* partial, int splits, const float* sa, const float* sb,
+                                         void* residual, const void* weight, float epsilon, int num_tokens, int hidden_size,
+                                         int dtype, float* absmax, nmx_stream_t stream);
+int nmx_silu_and_mul_splitk_scaled(void* out, const float* partial, int splits, const float* sa, const float* sb, int num_tokens,
+                                   int d, int dtype, float* absmax, nmx_stream_t stream);
+int nmx_rope_reshape_and_cache_scaled(const int64_t* positions, void* qkv, const float* partial, int splits, const float* sa,
+                                      const float* sb, const void* cos_sin_cache, void* key_cache, void* value_cache,
+                                      const int64_t* slot_mapping, int num_tokens, int num_heads, int num_kv_heads,
+                                      int head_size, int block_size, int dtype, int kv_dtype, float kv_scale,
+                                      nmx_stream_t stream);
 /* rotary_embedding (NeoX, rot_dim == head_size; csrc/pos_encoding_kernels.cu:10-96) on the q and k heads of a fused
  * qkv row [q heads | k heads | v heads] followed by reshape_and_cache (csrc/cache_kernels.cu:153-278) of the rotated k
  * and the v heads, in ONE launch. splits == 1: qkv [num_tokens, (H + 2 KVH) * D] is rotated in place; splits >= 2: the

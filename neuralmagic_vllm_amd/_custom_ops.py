@@ -498,15 +498,19 @@ def marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tenso
 # ---------------------------------------------------------------------------------------------------------
 class DeferredGemm:
     """Output of gptq_marlin_gemm_deferred: `out` [M, N] (valid iff splits == 1), else `partial` [splits, M, N] fp32."""
-    __slots__ = ("out", "partial", "splits")
+    __slots__ = ("out", "partial", "splits", "sa", "sb")
 
-    def __init__(self, out, partial, splits):
+    def __init__(self, out, partial, splits, sa=None, sb=None):
         self.out, self.partial, self.splits = out, partial, splits
+        self.sa, self.sb = sa, sb  # per-tensor scales of a deferred fp8 scaled_mm (applied by the consumer), else None
 
     def materialize(self) -> torch.Tensor:
         """Plain reduction (what the reduce launch would have produced), for consumers without a fused form."""
         if self.splits > 1:
-            self.out.copy_(self.partial.sum(dim=0))
+            acc = self.partial.sum(dim=0)
+            if self.sa is not None:
+                acc = self.sa * (self.sb * acc)
+            self.out.copy_(acc)
             self.splits = 1
         return self.out
 
@@ -535,24 +539,45 @@ def gptq_marlin_gemm_deferred(a: torch.Tensor, b_q_weight: torch.Tensor, b_scale
     return DeferredGemm(c, None, 1)
 
 
-def fused_add_rms_norm_splitk(g: DeferredGemm, residual: torch.Tensor, weight: torch.Tensor, epsilon: float) -> torch.Tensor:
-    """fused_add_rms_norm(g.out, residual, ...) on the deferred GEMM output; returns the normed tensor (g.out's storage)."""
-    if g.splits == 1:
-        fused_add_rms_norm(g.out, residual, weight, epsilon)
-        return g.out
+def fused_add_rms_norm_splitk(g: DeferredGemm, residual: torch.Tensor, weight: torch.Tensor, epsilon: float,
+                              want_absmax: bool = False):
+    """fused_add_rms_norm(g.out, residual, ...) on the deferred GEMM output; returns the normed tensor (g.out's storage), or
+    (normed, absmax [T] float32) with want_absmax (for scaled_fp8_quant_partials)."""
     out = g.out
-    _lib.check(_lib.lib().nmx_fused_add_rms_norm_splitk(_p(out), _p(g.partial), c_int(g.splits), _p(residual), _p(weight),
-                                                        c_f(epsilon), c_int(out.shape[0]), c_int(out.shape[1]),
-                                                        c_int(_dt(out)), _stream(out)))
-    return out
-
-
-def silu_and_mul_splitk(out: torch.Tensor, g: DeferredGemm) -> None:
     if g.splits == 1:
+        if want_absmax:
+            return out, fused_add_rms_norm_absmax(out, residual, weight, epsilon)
+        fused_add_rms_norm(out, residual, weight, epsilon)
+        return out
+    amax = torch.empty(out.shape[0], dtype=torch.float32, device=out.device) if want_absmax else None
+    if g.sa is not None or want_absmax:
+        _lib.check(_lib.lib().nmx_fused_add_rms_norm_splitk_scaled(
+            _p(out), _p(g.partial), c_int(g.splits), _p(g.sa), _p(g.sb), _p(residual), _p(weight), c_f(epsilon),
+            c_int(out.shape[0]), c_int(out.shape[1]), c_int(_dt(out)), _p(amax), _stream(out)))
+    else:
+        _lib.check(_lib.lib().nmx_fused_add_rms_norm_splitk(_p(out), _p(g.partial), c_int(g.splits), _p(residual), _p(weight),
+                                                            c_f(epsilon), c_int(out.shape[0]), c_int(out.shape[1]),
+                                                            c_int(_dt(out)), _stream(out)))
+    g.splits = 1
+    return (out, amax) if want_absmax else out
+
+
+def silu_and_mul_splitk(out: torch.Tensor, g: DeferredGemm, want_absmax: bool = False):
+    """silu_and_mul(out, g.out) on the deferred GEMM output; with want_absmax returns the per-token |max| of out."""
+    if g.splits == 1:
+        if want_absmax:
+            return silu_and_mul_absmax(out, g.out)
         silu_and_mul(out, g.out)
-        return
-    _lib.check(_lib.lib().nmx_silu_and_mul_splitk(_p(out), _p(g.partial), c_int(g.splits), c_int(out.shape[0]),
-                                                  c_int(out.shape[1]), c_int(_dt(out)), _stream(out)))
+        return None
+    T, d = out.shape
+    amax = torch.empty(T, dtype=torch.float32, device=out.device) if want_absmax else None
+    if g.sa is not None or want_absmax:
+        _lib.check(_lib.lib().nmx_silu_and_mul_splitk_scaled(_p(out), _p(g.partial), c_int(g.splits), _p(g.sa), _p(g.sb), c_int(T),
+                                                             c_int(d), c_int(_dt(out)), _p(amax), _stream(out)))
+    else:
+        _lib.check(_lib.lib().nmx_silu_and_mul_splitk(_p(out), _p(g.partial), c_int(g.splits), c_int(T), c_int(d), c_int(_dt(out)),
+                                                      _stream(out)))
+    return amax
 
 
 def rope_reshape_and_cache(positions: torch.Tensor, g, num_heads: int, num_kv_heads: int, head_size: int,
@@ -568,6 +593,13 @@ def rope_reshape_and_cache(positions: torch.Tensor, g, num_heads: int, num_kv_he
     if cos_sin_cache.shape[1] != head_size or cos_sin_cache.dtype != qkv.dtype:
         raise RuntimeError("rope_reshape_and_cache: rotary over the whole head, cache in the activation dtype")
     block_size = value_cache.shape[3]
+    if g.splits > 1 and g.sa is not None:
+        _lib.check(_lib.lib().nmx_rope_reshape_and_cache_scaled(
+            _p(positions), _p(qkv), _p(g.partial), c_int(g.splits), _p(g.sa), _p(g.sb), _p(cos_sin_cache), _p(key_cache),
+            _p(value_cache), _p(slot_mapping), c_int(qkv.shape[0]), c_int(num_heads), c_int(num_kv_heads), c_int(head_size),
+            c_int(block_size), c_int(_dt(qkv)), c_int(_kv(kv_cache_dtype)), c_f(kv_scale), _stream(qkv)))
+        g.splits = 1
+        return qkv
     _lib.check(_lib.lib().nmx_rope_reshape_and_cache(
         _p(positions), _p(qkv), _p(g.partial), c_int(g.splits), _p(cos_sin_cache), _p(key_cache), _p(value_cache),
         _p(slot_mapping), c_int(qkv.shape[0]), c_int(num_heads), c_int(num_kv_heads), c_int(head_size), c_int(block_size),
@@ -857,6 +889,34 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, s
                                         c_i64(a.stride(0)), c_i64(b.stride(1)), c_i64(out.stride(0)),
                                         c_int(int(a.dtype == torch.float8_e4m3fn)), c_int(_dt(out)), _stream(a)))
     return out
+
+
+def cutlass_scaled_mm_deferred(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                               out_dtype: Type[torch.dtype]) -> DeferredGemm:
+    """fp8 x fp8 cutlass_scaled_mm with per-tensor scales whose K-split reduce and scale epilogue are left to the consumer
+    op (fused_add_rms_norm_splitk / silu_and_mul_splitk / rope_reshape_and_cache). The slabs live in the stream's scratch
+    buffer: consume the result before the next op that uses that scratch."""
+    _dev(a)
+    if not (a.dtype == b.dtype == torch.float8_e4m3fn and a.dim() == 2 and b.dim() == 2 and a.size(1) == b.size(0)):
+        raise RuntimeError("cutlass_scaled_mm_deferred: fp8 a [M,K] and b [K,N] expected")
+    if a.stride(1) != 1 or b.stride(0) != 1:
+        raise RuntimeError("cutlass_scaled_mm_deferred: a row-major, b column-major")
+    if scale_a.numel() != 1 or scale_b.numel() != 1 or scale_a.dtype != torch.float32 or scale_b.dtype != torch.float32:
+        raise RuntimeError("cutlass_scaled_mm_deferred: per-tensor float32 scales only")
+    m, n, k = a.shape[0], b.shape[1], a.shape[1]
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    if m == 0:
+        return DeferredGemm(out, None, 1)
+    lib = _lib.lib()
+    scratch = _get_scratch(a.device, int(lib.nmx_scaled_mm_scratch_bytes(c_int(m), c_int(n), c_int(k))))
+    splits = c_int(1)
+    _lib.check(lib.nmx_scaled_mm_deferred(_p(out), _p(a), _p(b), _p(scale_a), _p(scale_b), _p(scratch), c_i64(scratch.numel()),
+                                          c_int(m), c_int(n), c_int(k), c_i64(a.stride(0)), c_i64(b.stride(1)),
+                                          c_i64(out.stride(0)), c_int(_dt(out)), ctypes.byref(splits), _stream(a)))
+    if splits.value > 1:
+        partial = scratch[:splits.value * m * n * 4].view(torch.float32).view(splits.value, m, n)
+        return DeferredGemm(out, partial, splits.value, scale_a, scale_b)
+    return DeferredGemm(out, None, 1)
 
 
 def scaled_fp8_quant(

@@ -313,12 +313,25 @@ int launch_act(void* out, const void* in, int num_tokens, int d, int act, bool g
 // them while loading its row: one dependent launch and one fp16 round trip less per GEMM. The sum runs in the order of
 // splitk_reduce_kernel (s = 0, 1, ...) and is rounded to scalar_t before any further arithmetic, so every result is
 // bit-identical to the unfused op sequence.
+// sa / sb (both or neither): per-tensor scales of a deferred fp8 scaled_mm, applied as its epilogue does - sa * (sb * sum)
+// (quant_ops.hip mm_epilogue4) - before the rounding to scalar_t.
 template <typename T>
-__device__ __forceinline__ void sum_partials8(const float* __restrict__ partial, int splits, int64_t slab, int64_t off, T (&e)[8]) {
+__device__ __forceinline__ void sum_partials8(const float* __restrict__ partial, int splits, int64_t slab, int64_t off, T (&e)[8],
+                                              const float* __restrict__ sa = nullptr, const float* __restrict__ sb = nullptr) {
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   for (int sidx = 0; sidx < splits; ++sidx) {
     a0 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off);
     a1 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off + 4);
+  }
+  if (sa != nullptr) {
+    const float va = sa[0], vb = sb[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0 = va * (vb * a0[j]), x1 = va * (vb * a1[j]);
+      asm volatile("" : "+v"(x0), "+v"(x1));  // fp32 rounding step of its own, as in mm_epilogue4 (no fusion with the conversion)
+      a0[j] = x0;
+      a1[j] = x1;
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -329,7 +342,8 @@ __device__ __forceinline__ void sum_partials8(const float* __restrict__ partial,
 
 // fused_add_rms_norm on x = round(sum_s partial[s]): residual += x; out = norm(residual) * weight (layernorm_kernels.cu:258-291)
 template <typename T, int VPT>
-__global__ void rms_norm_splitk_kernel(T* __restrict__ out, const float* __restrict__ partial, int splits, T* __restrict__ residual,
+__global__ void rms_norm_splitk_kernel(T* __restrict__ out, const float* __restrict__ partial, int splits, const float* __restrict__ sa,
+                                       const float* __restrict__ sb, float* __restrict__ absmax, T* __restrict__ residual,
                                        const T* __restrict__ weight, float eps, int hidden, int64_t slab) {
   __shared__ float smem[17];
   const int64_t row = (int64_t)blockIdx.x * hidden;
@@ -346,7 +360,7 @@ __global__ void rms_norm_splitk_kernel(T* __restrict__ out, const float* __restr
   for (int k = 0; k < VPT; ++k) {
     const int v = threadIdx.x + k * blockDim.x;
     if (v < nvec) {
-      sum_partials8<T>(partial, splits, slab, row + v * 8, x[k].e);
+      sum_partials8<T>(partial, splits, slab, row + v * 8, x[k].e, sa, sb);
       V r;
       r.u = *reinterpret_cast<const u32x4*>(residual + row + v * 8);
 #pragma unroll
@@ -361,31 +375,43 @@ __global__ void rms_norm_splitk_kernel(T* __restrict__ out, const float* __restr
   }
   var = block_sum(var, smem);
   const float sc = rsqrtf(var / (float)hidden + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int v = threadIdx.x + k * blockDim.x;
     if (v < nvec) {
       V o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * sc), w[k].e[j]);
+      for (int j = 0; j < 8; ++j) {
+        o.e[j] = rnd_mul<T>(Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) * sc), w[k].e[j]);
+        amax = fmaxf(amax, fabsf(Scalar<T>::to_f32(o.e[j])));
+      }
       *reinterpret_cast<u32x4*>(out + row + v * 8) = o.u;
     }
   }
+  if (absmax != nullptr) block_max_store(amax, smem, absmax + blockIdx.x);
 }
 
 // silu_and_mul on x = round(sum_s partial[s]) (activation_kernels.cu:12-30)
 template <typename T>
-__global__ void silu_and_mul_splitk_kernel(T* __restrict__ out, const float* __restrict__ partial, int splits, int d, int64_t slab) {
+__global__ void silu_and_mul_splitk_kernel(T* __restrict__ out, const float* __restrict__ partial, int splits, int d, int64_t slab,
+                                           const float* __restrict__ sa, const float* __restrict__ sb, float* __restrict__ absmax) {
+  __shared__ float smem[17];
   const int64_t tok = blockIdx.x;
   union V { u32x4 u; T e[8]; };
+  float amax = 0.f;
   for (int v = threadIdx.x; v < d / 8; v += blockDim.x) {
     V a, b, o;
-    sum_partials8<T>(partial, splits, slab, tok * 2 * d + v * 8, a.e);
-    sum_partials8<T>(partial, splits, slab, tok * 2 * d + d + v * 8, b.e);
+    sum_partials8<T>(partial, splits, slab, tok * 2 * d + v * 8, a.e, sa, sb);
+    sum_partials8<T>(partial, splits, slab, tok * 2 * d + d + v * 8, b.e, sa, sb);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<T>(act_fn<T, ACT_SILU>(a.e[j]), b.e[j]);
+    for (int j = 0; j < 8; ++j) {
+      o.e[j] = rnd_mul<T>(act_fn<T, ACT_SILU>(a.e[j]), b.e[j]);
+      amax = fmaxf(amax, fabsf(Scalar<T>::to_f32(o.e[j])));
+    }
     *reinterpret_cast<u32x4*>(out + tok * d + v * 8) = o.u;
   }
+  if (absmax != nullptr) block_max_store(amax, smem, absmax + blockIdx.x);
 }
 
 // rotary_embedding (NeoX, rot_dim == head_size) on the q and k heads of a fused qkv row + reshape_and_cache of the
@@ -394,7 +420,7 @@ __global__ void silu_and_mul_splitk_kernel(T* __restrict__ out, const float* __r
 // One thread = 8 consecutive rotary indices of one head: the x run and the y run (8 elements each).
 template <typename T, int KV>
 __global__ void rope_cache_kernel(const int64_t* __restrict__ positions, T* __restrict__ qkv, const float* __restrict__ partial,
-                                  int splits, int64_t slab, const T* __restrict__ cos_sin_cache, void* __restrict__ key_cache,
+                                  int splits, int64_t slab, const float* __restrict__ sa, const float* __restrict__ sb, const T* __restrict__ cos_sin_cache, void* __restrict__ key_cache,
                                   void* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int num_heads,
                                   int num_kv_heads, int head_size, int block_size, float kv_scale) {
   using cache_t = typename std::conditional<KV == NMX_KV_AUTO, T, uint8_t>::type;
@@ -415,8 +441,8 @@ __global__ void rope_cache_kernel(const int64_t* __restrict__ positions, T* __re
     const int64_t base = row + (int64_t)head * head_size;
     V x, y;
     if (splits > 1) {
-      sum_partials8<T>(partial, splits, slab, base + ro, x.e);
-      sum_partials8<T>(partial, splits, slab, base + embed + ro, y.e);
+      sum_partials8<T>(partial, splits, slab, base + ro, x.e, sa, sb);
+      sum_partials8<T>(partial, splits, slab, base + embed + ro, y.e, sa, sb);
     } else {
       x.u = *reinterpret_cast<const u32x4*>(qkv + base + ro);
       y.u = *reinterpret_cast<const u32x4*>(qkv + base + embed + ro);
@@ -566,11 +592,11 @@ extern "C" int nmx_activation(void* out, const void* input, int num_tokens, int 
 // ---- fused consumers of deferred split-K partials (no reference counterpart: the reference runs the ops one by one;
 //      results are bit-identical to nmx_fused_add_rms_norm / nmx_act_and_mul / nmx_rotary_embedding + nmx_reshape_and_cache
 //      applied to the reduced GEMM output) -----------------------------------------------------------------------------
-extern "C" int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int splits, void* residual,
-                                             const void* weight, float epsilon, int num_tokens, int hidden_size, int dtype,
-                                             nmx_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int add_rms_norm_splitk_common(void* input_out, const float* partial, int splits, const float* sa, const float* sb,
+                                      void* residual, const void* weight, float epsilon, int num_tokens, int hidden_size,
+                                      int dtype, float* absmax, hipStream_t stream) {
   if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK((sa == nullptr) == (sb == nullptr), NMX_ERR_INVALID_ARG, "splitk consumer: both scales or neither");
   NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "fused_add_rms_norm_splitk: fp16 / bf16 only");
   NMX_CHECK(splits >= 2 && partial != nullptr, NMX_ERR_INVALID_ARG, "fused_add_rms_norm_splitk needs >= 2 partial slabs");
   NMX_CHECK(hidden_size % 8 == 0 && hidden_size / 8 <= 2048 &&
@@ -581,7 +607,7 @@ extern "C" int nmx_fused_add_rms_norm_splitk(void* input_out, const float* parti
   if (nvec > 256) threads = std::min(1024, ((nvec / 2 + 63) / 64) * 64);
   const int vpt = (nvec + threads - 1) / threads;
   const int64_t slab = (int64_t)num_tokens * hidden_size;
-#define NMX_RS(T, V) rms_norm_splitk_kernel<T, V><<<num_tokens, threads, 0, stream>>>((T*)input_out, partial, splits, (T*)residual, (const T*)weight, epsilon, hidden_size, slab)
+#define NMX_RS(T, V) rms_norm_splitk_kernel<T, V><<<num_tokens, threads, 0, stream>>>((T*)input_out, partial, splits, sa, sb, absmax, (T*)residual, (const T*)weight, epsilon, hidden_size, slab)
   if (dtype == NMX_F16) { if (vpt == 1) NMX_RS(f16, 1); else NMX_RS(f16, 2); }
   else { if (vpt == 1) NMX_RS(bf16, 1); else NMX_RS(bf16, 2); }
 #undef NMX_RS
@@ -589,28 +615,54 @@ extern "C" int nmx_fused_add_rms_norm_splitk(void* input_out, const float* parti
   return NMX_OK;
 }
 
-extern "C" int nmx_silu_and_mul_splitk(void* out, const float* partial, int splits, int num_tokens, int d, int dtype,
-                                       nmx_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+extern "C" int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int splits, void* residual,
+                                             const void* weight, float epsilon, int num_tokens, int hidden_size, int dtype,
+                                             nmx_stream_t stream) {
+  return add_rms_norm_splitk_common(input_out, partial, splits, nullptr, nullptr, residual, weight, epsilon, num_tokens, hidden_size,
+                                    dtype, nullptr, (hipStream_t)stream);
+}
+
+// ... of a deferred fp8 scaled_mm: x = round(sa[0] * (sb[0] * sum_s partial[s])) (its epilogue), and optionally the per-token
+// |max| of the normed output for nmx_scaled_fp8_quant_partials (absmax may be null)
+extern "C" int nmx_fused_add_rms_norm_splitk_scaled(void* input_out, const float* partial, int splits, const float* sa,
+                                                    const float* sb, void* residual, const void* weight, float epsilon,
+                                                    int num_tokens, int hidden_size, int dtype, float* absmax,
+                                                    nmx_stream_t stream) {
+  return add_rms_norm_splitk_common(input_out, partial, splits, sa, sb, residual, weight, epsilon, num_tokens, hidden_size, dtype,
+                                    absmax, (hipStream_t)stream);
+}
+
+static int silu_and_mul_splitk_common(void* out, const float* partial, int splits, const float* sa, const float* sb, int num_tokens,
+                                      int d, int dtype, float* absmax, hipStream_t stream) {
   if (num_tokens == 0 || d == 0) return NMX_OK;
+  NMX_CHECK((sa == nullptr) == (sb == nullptr), NMX_ERR_INVALID_ARG, "splitk consumer: both scales or neither");
   NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "silu_and_mul_splitk: fp16 / bf16 only");
   NMX_CHECK(splits >= 2 && partial != nullptr && d % 8 == 0 && (((uintptr_t)out | (uintptr_t)partial) % 16 == 0),
             NMX_ERR_INVALID_ARG, "silu_and_mul_splitk: >= 2 slabs, d %% 8 == 0, 16-byte aligned operands");
   const int threads = std::min(1024, std::max(64, ((d / 8 + 63) / 64) * 64));
   const int64_t slab = (int64_t)num_tokens * 2 * d;
-  if (dtype == NMX_F16) silu_and_mul_splitk_kernel<f16><<<num_tokens, threads, 0, stream>>>((f16*)out, partial, splits, d, slab);
-  else silu_and_mul_splitk_kernel<bf16><<<num_tokens, threads, 0, stream>>>((bf16*)out, partial, splits, d, slab);
+  if (dtype == NMX_F16) silu_and_mul_splitk_kernel<f16><<<num_tokens, threads, 0, stream>>>((f16*)out, partial, splits, d, slab, sa, sb, absmax);
+  else silu_and_mul_splitk_kernel<bf16><<<num_tokens, threads, 0, stream>>>((bf16*)out, partial, splits, d, slab, sa, sb, absmax);
   NMX_LAUNCH_CHECK();
   return NMX_OK;
 }
 
-extern "C" int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, const float* partial, int splits,
-                                          const void* cos_sin_cache, void* key_cache, void* value_cache,
-                                          const int64_t* slot_mapping, int num_tokens, int num_heads, int num_kv_heads,
-                                          int head_size, int block_size, int dtype, int kv_dtype, float kv_scale,
-                                          nmx_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+extern "C" int nmx_silu_and_mul_splitk(void* out, const float* partial, int splits, int num_tokens, int d, int dtype,
+                                       nmx_stream_t stream) {
+  return silu_and_mul_splitk_common(out, partial, splits, nullptr, nullptr, num_tokens, d, dtype, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nmx_silu_and_mul_splitk_scaled(void* out, const float* partial, int splits, const float* sa, const float* sb,
+                                              int num_tokens, int d, int dtype, float* absmax, nmx_stream_t stream) {
+  return silu_and_mul_splitk_common(out, partial, splits, sa, sb, num_tokens, d, dtype, absmax, (hipStream_t)stream);
+}
+
+static int rope_cache_common(const int64_t* positions, void* qkv, const float* partial, int splits, const float* sa, const float* sb,
+                             const void* cos_sin_cache, void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                             int num_tokens, int num_heads, int num_kv_heads, int head_size, int block_size, int dtype, int kv_dtype,
+                             float kv_scale, hipStream_t stream) {
   if (num_tokens == 0) return NMX_OK;
+  NMX_CHECK((sa == nullptr) == (sb == nullptr), NMX_ERR_INVALID_ARG, "splitk consumer: both scales or neither");
   NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "rope_reshape_and_cache: fp16 / bf16 only");
   NMX_CHECK(head_size % 16 == 0 && num_heads > 0 && num_kv_heads > 0, NMX_ERR_INVALID_ARG,
             "rope_reshape_and_cache: head_size %% 16 == 0 (NeoX rotary over the whole head)");
@@ -622,7 +674,7 @@ extern "C" int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, c
   const int threads = std::min(128, std::max(64, ((nvec + 63) / 64) * 64));
   const dim3 grid(num_tokens, std::min(8, ceil_div(nvec, threads)));
   const int64_t slab = (int64_t)num_tokens * heads * head_size;
-#define NMX_RC(T, KVC) rope_cache_kernel<T, KVC><<<grid, threads, 0, stream>>>(positions, (T*)qkv, partial, splits, slab, (const T*)cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads, head_size, block_size, kv_scale)
+#define NMX_RC(T, KVC) rope_cache_kernel<T, KVC><<<grid, threads, 0, stream>>>(positions, (T*)qkv, partial, splits, slab, sa, sb, (const T*)cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads, head_size, block_size, kv_scale)
 #define NMX_RC_T(T)                                                                       \
   switch (kv_dtype) {                                                                     \
     case NMX_KV_AUTO: NMX_RC(T, NMX_KV_AUTO); break;                                      \
@@ -635,4 +687,22 @@ extern "C" int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, c
 #undef NMX_RC
   NMX_LAUNCH_CHECK();
   return NMX_OK;
+}
+
+extern "C" int nmx_rope_reshape_and_cache(const int64_t* positions, void* qkv, const float* partial, int splits,
+                                          const void* cos_sin_cache, void* key_cache, void* value_cache,
+                                          const int64_t* slot_mapping, int num_tokens, int num_heads, int num_kv_heads,
+                                          int head_size, int block_size, int dtype, int kv_dtype, float kv_scale,
+                                          nmx_stream_t stream) {
+  return rope_cache_common(positions, qkv, partial, splits, nullptr, nullptr, cos_sin_cache, key_cache, value_cache, slot_mapping,
+                           num_tokens, num_heads, num_kv_heads, head_size, block_size, dtype, kv_dtype, kv_scale, (hipStream_t)stream);
+}
+
+extern "C" int nmx_rope_reshape_and_cache_scaled(const int64_t* positions, void* qkv, const float* partial, int splits,
+                                                 const float* sa, const float* sb, const void* cos_sin_cache, void* key_cache,
+                                                 void* value_cache, const int64_t* slot_mapping, int num_tokens, int num_heads,
+                                                 int num_kv_heads, int head_size, int block_size, int dtype, int kv_dtype,
+                                                 float kv_scale, nmx_stream_t stream) {
+  return rope_cache_common(positions, qkv, partial, splits, sa, sb, cos_sin_cache, key_cache, value_cache, slot_mapping, num_tokens,
+                           num_heads, num_kv_heads, head_size, block_size, dtype, kv_dtype, kv_scale, (hipStream_t)stream);
 }

@@ -145,6 +145,7 @@ struct MmParams {
   int a_per_row, b_per_col;
   int k_splits;
   void* partial;  // [k_splits][M][N] fp32 (fp8) / int32 (int8)
+  int defer_reduce;  // leave the raw slabs for the consumer op (no reduce launch)
 };
 
 // four consecutive output columns n .. n + 3 of row m: scales, bias, ONE 8-byte store (n % 4 == 0, ldc % 16 == 0)
@@ -155,7 +156,11 @@ __device__ __forceinline__ void mm_epilogue4(const MmParams& p, acc_t acc, int m
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float sb = p.b_scales[p.b_per_col ? n + r : 0];
-    const float v = sa * (sb * (float)acc[r]);  // tests/kernels/test_cutlass.py:35-47
+    float v = sa * (sb * (float)acc[r]);  // tests/kernels/test_cutlass.py:35-47
+    // keep the fp32 product a rounding step of its own: hipcc otherwise fuses the last multiply with the conversion
+    // (v_fma_mixlo_f16: ONE rounding of the exact product), which differs from the reference's float epilogue +
+    // NumericConverter on exact ties - and from the consumer ops that apply the same epilogue to deferred slabs
+    asm volatile("" : "+v"(v));
     o.h[r] = Scalar<out_t>::from_f32(v);
   }
   if (p.bias != nullptr) {
@@ -741,7 +746,7 @@ int launch_mm_tile(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
     kern<<<grid, 256, smem, stream>>>(p);
   }
   NMX_LAUNCH_CHECK();
-  if (p.k_splits > 1) {
+  if (p.k_splits > 1 && !p.defer_reduce) {
     const int64_t mn4 = (int64_t)p.M * p.N / 4;
     scaled_mm_reduce_kernel<out_t, FP8><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(p);
     NMX_LAUNCH_CHECK();
@@ -789,7 +794,7 @@ int launch_mm(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t str
     }
   }
   NMX_LAUNCH_CHECK();
-  if (p.k_splits > 1) {
+  if (p.k_splits > 1 && !p.defer_reduce) {
     const int64_t mn4 = (int64_t)p.M * p.N / 4;
     scaled_mm_reduce_kernel<out_t, FP8><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(p);
     NMX_LAUNCH_CHECK();
@@ -886,10 +891,11 @@ extern "C" int64_t nmx_scaled_mm_scratch_bytes(int m, int n, int k) {
   return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
 }
 
-extern "C" int nmx_scaled_mm(void* out, const void* a, const void* b, const float* a_scales, int a_scales_numel,
-                             const float* b_scales, int b_scales_numel, const void* bias, void* scratch,
-                             int64_t scratch_bytes, int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int is_fp8,
-                             int out_dtype, nmx_stream_t stream) {
+static int scaled_mm_common(void* out, const void* a, const void* b, const float* a_scales, int a_scales_numel,
+                            const float* b_scales, int b_scales_numel, const void* bias, void* scratch, int64_t scratch_bytes,
+                            int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int is_fp8, int out_dtype, bool defer,
+                            int* splits_out, hipStream_t stream) {
+  if (splits_out != nullptr) *splits_out = 1;
   // checks mirror cutlass_w8a8/scaled_mm_entry.cu:59-76
   NMX_CHECK(a_scales_numel == 1 || a_scales_numel == m, NMX_ERR_INVALID_ARG, "a_scales.numel() must be 1 or a.size(0)");
   NMX_CHECK(b_scales_numel == 1 || b_scales_numel == n, NMX_ERR_INVALID_ARG, "b_scales.numel() must be 1 or b.size(1)");
@@ -902,12 +908,33 @@ extern "C" int nmx_scaled_mm(void* out, const void* a, const void* b, const floa
   NMX_CHECK((int64_t)n * ldb < (1ll << 31) && (int64_t)m * lda < (1ll << 31), NMX_ERR_UNSUPPORTED,
             "scaled_mm: operands of 2 GiB or more are not supported");
   MmParams p{(const uint8_t*)a, (const uint8_t*)b, out, a_scales, b_scales, bias, m, n, k, lda, ldb, ldc,
-             a_scales_numel > 1 ? 1 : 0, b_scales_numel > 1 ? 1 : 0, 1, nullptr};
+             a_scales_numel > 1 ? 1 : 0, b_scales_numel > 1 ? 1 : 0, 1, nullptr, defer ? 1 : 0};
+  int rc;
   if (out_dtype == NMX_F16)
-    return is_fp8 ? launch_mm<f16, true>(p, scratch, scratch_bytes, (hipStream_t)stream)
-                  : launch_mm<f16, false>(p, scratch, scratch_bytes, (hipStream_t)stream);
-  return is_fp8 ? launch_mm<bf16, true>(p, scratch, scratch_bytes, (hipStream_t)stream)
-                : launch_mm<bf16, false>(p, scratch, scratch_bytes, (hipStream_t)stream);
+    rc = is_fp8 ? launch_mm<f16, true>(p, scratch, scratch_bytes, stream) : launch_mm<f16, false>(p, scratch, scratch_bytes, stream);
+  else
+    rc = is_fp8 ? launch_mm<bf16, true>(p, scratch, scratch_bytes, stream) : launch_mm<bf16, false>(p, scratch, scratch_bytes, stream);
+  if (rc == NMX_OK && splits_out != nullptr) *splits_out = p.k_splits;
+  return rc;
+}
+
+extern "C" int nmx_scaled_mm(void* out, const void* a, const void* b, const float* a_scales, int a_scales_numel,
+                             const float* b_scales, int b_scales_numel, const void* bias, void* scratch,
+                             int64_t scratch_bytes, int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int is_fp8,
+                             int out_dtype, nmx_stream_t stream) {
+  return scaled_mm_common(out, a, b, a_scales, a_scales_numel, b_scales, b_scales_numel, bias, scratch, scratch_bytes, m, n, k, lda,
+                          ldb, ldc, is_fp8, out_dtype, false, nullptr, (hipStream_t)stream);
+}
+
+// fp8 x fp8 with per-tensor scales and no bias, the K-split reduce AND the scale epilogue left to the consumer op
+// (nmx_fused_add_rms_norm_splitk / nmx_silu_and_mul_splitk / nmx_rope_reshape_and_cache with their scale pointers): the raw
+// fp32 slabs [*splits_out, m, n] stay in `scratch`; out is written (complete) only when *splits_out == 1.
+extern "C" int nmx_scaled_mm_deferred(void* out, const void* a, const void* b, const float* a_scale, const float* b_scale,
+                                      void* scratch, int64_t scratch_bytes, int m, int n, int k, int64_t lda, int64_t ldb,
+                                      int64_t ldc, int out_dtype, int* splits_out, nmx_stream_t stream) {
+  NMX_CHECK(splits_out != nullptr, NMX_ERR_INVALID_ARG, "scaled_mm_deferred: splits_out must be non-null");
+  return scaled_mm_common(out, a, b, a_scale, 1, b_scale, 1, nullptr, scratch, scratch_bytes, m, n, k, lda, ldb, ldc, 1, out_dtype,
+                          true, splits_out, (hipStream_t)stream);
 }
 
 extern "C" int nmx_scaled_mm_supports_fp8(int capability) {

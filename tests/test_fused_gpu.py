@@ -215,3 +215,35 @@ def test_deferred_marlin_24_gemm(ops, M):
     fused = ops.fused_add_rms_norm_splitk(g, res_b, wn, 1e-5)
     torch.cuda.synchronize()
     assert torch.equal(_bits(fused), _bits(plain)) and torch.equal(_bits(res_a), _bits(res_b))
+
+
+@pytest.mark.parametrize("M", [1, 16, 64, 256])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (14336, 4096), (4096, 6144)])
+def test_deferred_fp8_scaled_mm_consumers(ops, M, K, N):
+    """fp8 cutlass_scaled_mm with the reduce + scale epilogue deferred: every fused consumer equals the plain sequence bit
+    for bit (sum in the reduce kernel's order, sa * (sb * sum) as its epilogue, one rounding), maxima included."""
+    seed_all(M + N)
+    a = (torch.randn(M, K, device=DEV)).to(torch.float8_e4m3fn)
+    b = (torch.randn(N, K, device=DEV)).to(torch.float8_e4m3fn)
+    sa = torch.tensor([0.013], device=DEV)
+    sb = torch.tensor([0.021], device=DEV)
+    plain = ops.cutlass_scaled_mm(a, b.t(), sa, sb, torch.float16)
+    g = ops.cutlass_scaled_mm_deferred(a, b.t(), sa, sb, torch.float16)
+    res0 = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    w = (torch.rand(N, device=DEV) + 0.5).half()
+    res_a, res_b = res0.clone(), res0.clone()
+    ops.fused_add_rms_norm(plain, res_a, w, 1e-5)
+    fused, amax = ops.fused_add_rms_norm_splitk(g, res_b, w, 1e-5, want_absmax=True)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(fused), _bits(plain)) and torch.equal(_bits(res_a), _bits(res_b))
+    assert torch.equal(amax, plain.float().abs().amax(dim=1))
+    # gated activation consumer on a fresh deferred result
+    plain2 = ops.cutlass_scaled_mm(a, b.t(), sa, sb, torch.float16)
+    g2 = ops.cutlass_scaled_mm_deferred(a, b.t(), sa, sb, torch.float16)
+    out_a = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
+    out_b = torch.empty_like(out_a)
+    ops.silu_and_mul(out_a, plain2)
+    amax2 = ops.silu_and_mul_splitk(out_b, g2, want_absmax=True)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(out_a), _bits(out_b))
+    assert torch.equal(amax2, out_a.float().abs().amax(dim=1))
