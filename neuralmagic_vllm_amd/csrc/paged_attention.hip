@@ -480,6 +480,7 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
       }
   }
   const float slope = (p.alibi_slopes != nullptr && q_valid) ? p.alibi_slopes[head] : 0.f;
+  const bool has_alibi = p.alibi_slopes != nullptr;
   int bs_block_offset = 0, q_bs_block_id = 0;
   if (p.sparse) {
     q_bs_block_id = (seq_len - 1) / p.bs_block_size;
@@ -549,50 +550,71 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
       }
     }
 
-    bool msk[4][4];
-    float m_tile = -FLT_MAX;
+    // Softmax of the tile, ~3 VALU per logit on the common path (this kernel was VALU-busy 68 %): tiles that lie wholly
+    // inside the sequence, without alibi / block-sparse masks, need no per-element masks and fold the scale into one fma
+    // per logit (exp2(s * scale * log2e - m * log2e)); the row maximum is reduced with permlane swaps instead of two LDS
+    // round trips; the running maximum is LAZY - accumulators are rescaled only when a row's maximum grows by more than 5
+    // (P stays < e^5, well inside fp16 / bf16 range; the waves' (m, l, O) triples are merged with their own maxima below).
+    constexpr float LOG2E = 1.4426950408889634f;
+    const bool fast = !p.sparse && !has_alibi && t0 + TILE <= seq_len;
+    float e[4][4];
+    float m_tile;
+    bool msk[4][4] = {};
+    if (fast) {
+      float mx = s[0][0];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int tok = t0 + tau(u, 4 * g + r);
-        float v = s[u][r] * p.scale;
-        v += (slope != 0.f) ? slope * (float)(tok - seq_len + 1) : 0.f;
-        bool masked = tok >= seq_len;
-        if (p.sparse) {
-          const int kb_id = ((tok >> p.bs_shift) << p.bs_shift) / p.bs_block_size;
-          const bool is_remote = ((kb_id + bs_block_offset) % p.bs_vert_stride) == 0;
-          const bool is_local = kb_id > q_bs_block_id - p.bs_local_blocks;
-          masked = masked || !(is_remote || is_local);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][r]);
+      m_tile = mx * p.scale;
+    } else {
+      m_tile = -FLT_MAX;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tok = t0 + tau(u, 4 * g + r);
+          float v = s[u][r] * p.scale;
+          v += (slope != 0.f) ? slope * (float)(tok - seq_len + 1) : 0.f;
+          bool masked = tok >= seq_len;
+          if (p.sparse) {
+            const int kb_id = ((tok >> p.bs_shift) << p.bs_shift) / p.bs_block_size;
+            const bool is_remote = ((kb_id + bs_block_offset) % p.bs_vert_stride) == 0;
+            const bool is_local = kb_id > q_bs_block_id - p.bs_local_blocks;
+            masked = masked || !(is_remote || is_local);
+          }
+          msk[u][r] = masked;
+          s[u][r] = v;
+          m_tile = masked ? m_tile : fmaxf(m_tile, v);
         }
-        msk[u][r] = masked;
-        s[u][r] = v;
-        m_tile = masked ? m_tile : fmaxf(m_tile, v);
       }
     }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile);
-    const float alpha = __expf(m_run - m_new);
-    m_run = m_new;
-
-    float psum = 0.f;
+    {
+      auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_tile), __float_as_uint(m_tile), false, false);
+      m_tile = fmaxf(__uint_as_float(x[0]), __uint_as_float(x[1]));
+      auto y = __builtin_amdgcn_permlane16_swap(__float_as_uint(m_tile), __float_as_uint(m_tile), false, false);
+      m_tile = fmaxf(__uint_as_float(y[0]), __uint_as_float(y[1]));
+    }
+    if (__any(m_tile - m_run > 5.f)) {
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      l_part *= alpha;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+    }
+    const float c = (fast ? p.scale : 1.f) * LOG2E, mc = -m_run * LOG2E;
     u32x2 pk[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      float e[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        e[r] = msk[u][r] ? 0.f : __expf(s[u][r] - m_new);
-        psum += e[r];
+        const float x = __builtin_amdgcn_exp2f(fmaf(s[u][r], c, mc));
+        e[u][r] = msk[u][r] ? 0.f : x;
       }
-      pk[u][0] = pack2<scalar_t>(e[0], e[1]);
-      pk[u][1] = pack2<scalar_t>(e[2], e[3]);
-    }
-    l_part = l_part * alpha + psum;
-    if (__any(alpha != 1.0f)) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+      l_part += (e[u][0] + e[u][1]) + (e[u][2] + e[u][3]);
+      pk[u][0] = pack2<scalar_t>(e[u][0], e[u][1]);
+      pk[u][1] = pack2<scalar_t>(e[u][2], e[u][3]);
     }
 
     const u32x4 pb_a = p_to_operand(pk[0], pk[1]);
