@@ -191,6 +191,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
   }
 
   const float slope = (p.alibi_slopes != nullptr && q_valid) ? p.alibi_slopes[head] : 0.f;
+  const bool has_alibi = p.alibi_slopes != nullptr;
   // block-sparse (attention_kernels.cu:209-256)
   int bs_block_offset = 0, q_bs_block_id = 0;
   if (p.sparse) {
@@ -294,52 +295,68 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
       for (int ks = 0; ks < KS; ++ks) s[u] = mfma_16x16x32<scalar_t>(kf[u][ks], qf[ks], s[u]);
     }
 
-    // ---- logits, mask, online softmax ----
-    bool msk[2][4];
-    float m_tile = -FLT_MAX;
+    // ---- logits, mask, online softmax (the scheme of paged_attention_fp8w_kernel: mask-free path for tiles inside the
+    //      sequence, permlane reduction, lazy running maximum) ----
+    constexpr float LOG2E = 1.4426950408889634f;
+    const bool fast = !p.sparse && !has_alibi && t0 + kTile <= seq_len;
+    bool msk[2][4] = {};
+    float m_tile;
+    if (fast) {
+      float mx = s[0][0];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int tok = t0 + 16 * u + 4 * g + r;
-        float v = s[u][r] * p.scale;
-        v += (slope != 0.f) ? slope * (float)(tok - seq_len + 1) : 0.f;
-        bool masked = tok >= seq_len;
-        if (p.sparse) {
-          const int kb_id = ((tok >> p.bs_shift) << p.bs_shift) / p.bs_block_size;
-          const bool is_remote = ((kb_id + bs_block_offset) % p.bs_vert_stride) == 0;
-          const bool is_local = kb_id > q_bs_block_id - p.bs_local_blocks;
-          masked = masked || !(is_remote || is_local);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][r]);
+      m_tile = mx * p.scale;
+    } else {
+      m_tile = -FLT_MAX;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tok = t0 + 16 * u + 4 * g + r;
+          float v = s[u][r] * p.scale;
+          v += (slope != 0.f) ? slope * (float)(tok - seq_len + 1) : 0.f;
+          bool masked = tok >= seq_len;
+          if (p.sparse) {
+            const int kb_id = ((tok >> p.bs_shift) << p.bs_shift) / p.bs_block_size;
+            const bool is_remote = ((kb_id + bs_block_offset) % p.bs_vert_stride) == 0;
+            const bool is_local = kb_id > q_bs_block_id - p.bs_local_blocks;
+            masked = masked || !(is_remote || is_local);
+          }
+          msk[u][r] = masked;
+          s[u][r] = v;
+          m_tile = masked ? m_tile : fmaxf(m_tile, v);
         }
-        msk[u][r] = masked;
-        s[u][r] = v;
-        m_tile = masked ? m_tile : fmaxf(m_tile, v);
       }
     }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile);
-    const float alpha = __expf(m_run - m_new);
-    m_run = m_new;
-
-    float psum = 0.f;
+    {
+      auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_tile), __float_as_uint(m_tile), false, false);
+      m_tile = fmaxf(__uint_as_float(x[0]), __uint_as_float(x[1]));
+      auto y = __builtin_amdgcn_permlane16_swap(__float_as_uint(m_tile), __float_as_uint(m_tile), false, false);
+      m_tile = fmaxf(__uint_as_float(y[0]), __uint_as_float(y[1]));
+    }
+    if (__any(m_tile - m_run > 5.f)) {
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      l_part *= alpha;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+    }
+    const float c = (fast ? p.scale : 1.f) * LOG2E, mc = -m_run * LOG2E;
     u32x2 pk[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       float e[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        e[r] = msk[u][r] ? 0.f : __expf(s[u][r] - m_new);
-        psum += e[r];
+        const float x = __builtin_amdgcn_exp2f(fmaf(s[u][r], c, mc));
+        e[r] = msk[u][r] ? 0.f : x;
       }
+      l_part += (e[0] + e[1]) + (e[2] + e[3]);
       pk[u][0] = pack2<scalar_t>(e[0], e[1]);
       pk[u][1] = pack2<scalar_t>(e[2], e[3]);
-    }
-    l_part = l_part * alpha + psum;
-
-    if (__any(alpha != 1.0f)) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
     }
 
     // ---- O^T += V^T . P^T ----
