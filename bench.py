@@ -99,6 +99,7 @@ def parse():
                     "load-time repack + zero-point Marlin kernel that AWQLinearMethod uses")
     ap.add_argument("--attn", choices=["auto", "v1", "v2"], default="auto", help="decode attention op: auto = the reference's rule "
                     "(paged_attn.py:120-121)")
+    ap.add_argument("--no-act-fuse", action="store_true", help="int4: gate_up GEMM and silu_and_mul as two ops (A/B of the fused epilogue)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
@@ -148,6 +149,7 @@ class Llama3Decode:
         self.awq_marlin = awq_marlin  # AWQ configs: weights repacked at load (the layer's path); False = the raw awq_gemm op
         self.all_reduce, self.all_gather = all_reduce, all_gather  # tensor-parallel collectives (None: TP = 1)
         self.fuse = False  # int4 only: deferred split-K reduction + rotary / cache fusion (set by main)
+        self.act_fuse = True  # int4: gate_up + silu_and_mul as one op (set by main)
         self.n_layers = n_layers
         self.variant = variant
         self.kv_dtype = VARIANTS[variant]["kv"]
@@ -272,8 +274,13 @@ class Llama3Decode:
             if self.all_reduce is not None:
                 self.all_reduce(o.materialize())
             h = ops.fused_add_rms_norm_splitk(o, resid, lw["ln2"], 1e-5)
-            act = torch.empty(h.shape[0], cfg["inter"], dtype=h.dtype, device=h.device)
-            ops.silu_and_mul_splitk(act, gemm(h, lw["gate_up"], "gate_up"))
+            if self.variant == "int4" and self.act_fuse:  # the activation runs in the GEMM's epilogue where the launch has no K split
+                K, N = self.shapes["gate_up"]
+                w = lw["gate_up"]
+                act = ops.gptq_marlin_gemm_silu_and_mul(h, w[0], w[1], e, e, ws, 4, h.shape[0], N, K, True)
+            else:
+                act = torch.empty(h.shape[0], cfg["inter"], dtype=h.dtype, device=h.device)
+                ops.silu_and_mul_splitk(act, gemm(h, lw["gate_up"], "gate_up"))
             d = gemm(act, lw["down"], "down")
             if self.all_reduce is not None:
                 self.all_reduce(d.materialize())
@@ -584,6 +591,7 @@ def main():
     # AWQ (hidden 8192): one workgroup per token reading 2-4 fp32 slabs of a 32-KiB row is slower than the 512-workgroup
     # reduce launch until there are >= 128 rows (measured: batch 64 7.81 vs 7.71 ms, batch 256 12.61 vs 13.28 ms)
     awq_fusable = args.config.startswith("awq70b") and not args.awq_op and args.batch >= 128
+    model.act_fuse = not args.no_act_fuse
     model.fuse = (args.config in ("int4", "fp8", "sparse24") or awq_fusable) and not args.no_fuse and (args.config != "fp8" or tp == 0)
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()

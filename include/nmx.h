@@ -155,6 +155,15 @@ int nmx_gptq_marlin_gemm_deferred(const void* a, const int32_t* b_q_weight, cons
                                   const int32_t* perm, void* c, int64_t workspace_numel, void* scratch,
                                   int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits,
                                   int num_groups, int is_k_full, int dtype, int* splits_out, nmx_stream_t stream);
+/* gate_up projection + silu_and_mul as one op (LlamaMLP.forward, vllm/model_executor/models/llama.py:79-83: gate_up_proj
+ * then SiluAndMul): act_out [size_m, size_n / 2] = silu(c[:, :size_n/2]) * c[:, size_n/2:], c = gptq_marlin_gemm(...), both
+ * roundings of the two-op sequence kept (bit-identical). One launch where the dispatch takes the wide-tile kernel without a
+ * K split (c is then NOT written); otherwise the deferred GEMM + the consumer launch. c [size_m, size_n] and scratch as for
+ * nmx_gptq_marlin_gemm. */
+int nmx_gptq_marlin_gemm_silu_and_mul(const void* a, const int32_t* b_q_weight, const void* b_scales, const int32_t* g_idx,
+                                      const int32_t* perm, void* c, void* act_out, int64_t workspace_numel, void* scratch,
+                                      int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits,
+                                      int num_groups, int is_k_full, int dtype, nmx_stream_t stream);
 /* fused_add_rms_norm (csrc/layernorm_kernels.cu:258-291) on x = round(sum_s partial[s]): residual += x,
  * input_out = rms_norm(residual) * weight. partial [splits, num_tokens, hidden] fp32, splits >= 2. */
 int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int splits, void* residual, const void* weight,

@@ -539,6 +539,32 @@ def gptq_marlin_gemm_deferred(a: torch.Tensor, b_q_weight: torch.Tensor, b_scale
     return DeferredGemm(c, None, 1)
 
 
+def gptq_marlin_gemm_silu_and_mul(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor, g_idx: torch.Tensor,
+                                  perm: torch.Tensor, workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int,
+                                  size_k: int, is_k_full: bool) -> torch.Tensor:
+    """silu_and_mul(gptq_marlin_gemm(a, gate_up weight ...)) -> [size_m, size_n / 2] (LlamaMLP's gate_up_proj + SiluAndMul,
+    models/llama.py:79-83). One launch where the wide-tile kernel runs without a K split (the activation is its epilogue),
+    otherwise GEMM + consumer; bit-identical to the two ops either way (tests/test_fused_gpu.py)."""
+    _dev(a)
+    if a.dim() != 2 or a.shape[0] != size_m or a.shape[1] != size_k:
+        raise RuntimeError(f"Shape mismatch: a.size = {tuple(a.shape)}, size_m = {size_m}, size_k = {size_k}")
+    if not a.is_contiguous():
+        raise RuntimeError("A is not contiguous")
+    if size_n % 16 != 0:
+        raise RuntimeError(f"size_n = {size_n} must be a multiple of 16")
+    act = torch.empty((size_m, size_n // 2), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return act
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)  # only touched on the two-launch route
+    scratch = _marlin_scratch(a, size_m, size_n, size_k)
+    has_idx = g_idx is not None and g_idx.numel() > 0
+    _lib.check(_lib.lib().nmx_gptq_marlin_gemm_silu_and_mul(
+        _p(a), _p(b_q_weight), _p(b_scales), _p(g_idx if has_idx else None), _p(perm if has_idx else None), _p(c), _p(act),
+        c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n), c_int(size_k),
+        c_int(num_bits), c_int(b_scales.shape[0]), c_int(int(is_k_full)), c_int(_dt(a)), _stream(a)))
+    return act
+
+
 def fused_add_rms_norm_splitk(g: DeferredGemm, residual: torch.Tensor, weight: torch.Tensor, epsilon: float,
                               want_absmax: bool = False):
     """fused_add_rms_norm(g.out, residual, ...) on the deferred GEMM output; returns the normed tensor (g.out's storage), or

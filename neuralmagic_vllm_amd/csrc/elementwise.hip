@@ -38,10 +38,6 @@ __device__ __forceinline__ void block_max_store(float v, float* smem, float* dst
   }
 }
 
-template <typename T> __device__ __forceinline__ T rnd_mul(T a, T b) {  // scalar_t * scalar_t -> scalar_t
-  return Scalar<T>::from_f32(Scalar<T>::to_f32(a) * Scalar<T>::to_f32(b));
-}
-
 // rms_norm (layernorm_kernels.cu:22-46): out = scalar_t(x * rsqrt(mean(x^2) + eps)) * weight
 // fused_add_rms_norm (:258-291): z = input + residual (scalar_t); residual = z; input = scalar_t(z * s) * weight
 template <typename T, bool FUSED_ADD>
@@ -193,7 +189,7 @@ template <typename T, int ACT>
 __device__ __forceinline__ T act_fn(T xv) {
   const float f = Scalar<T>::to_f32(xv);
   if constexpr (ACT == ACT_SILU) {
-    return Scalar<T>::from_f32(f / (1.0f + expf(-f)));  // activation_kernels.cu:27-30
+    return silu_rnd<T>(xv);  // activation_kernels.cu:27-30
   } else if constexpr (ACT == ACT_GELU) {
     return Scalar<T>::from_f32(f * 0.5f * (1.0f + erff(f * 0.70710678118654752440f)));  // :33-40
   } else if constexpr (ACT == ACT_GELU_TANH) {

@@ -7,7 +7,8 @@ namespace {
 int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales, const int32_t* g_idx,
                   const int32_t* perm, void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes,
                   int size_m, int size_n, int size_k, int kind, int num_groups, int is_k_full, int dtype,
-                  hipStream_t stream, int defer_reduce = 0, int* splits_out = nullptr) {
+                  hipStream_t stream, int defer_reduce = 0, int* splits_out = nullptr, void* act_out = nullptr,
+                  int* act_done = nullptr) {
   // checks mirror gptq_marlin.cu:1741-1843
   NMX_CHECK(size_k % 16 == 0, NMX_ERR_INVALID_ARG, "size_k = %d is not divisible by tile_size = 16", size_k);
   NMX_CHECK(size_n % 64 == 0, NMX_ERR_INVALID_ARG, "size_n = %d is not divisible by min_thread_n = 64", size_n);
@@ -21,7 +22,9 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   p.a = a; p.b = b_q_weight; p.meta = nullptr; p.zeros = nullptr; p.scales = b_scales; p.g_idx = g_idx; p.perm = perm; p.c = c; p.partial = nullptr;
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.k_splits = 1; p.slow_act_order = 0;
   p.defer_reduce = defer_reduce;
+  p.act_out = act_out;
   if (splits_out != nullptr) *splits_out = 1;
+  if (act_done != nullptr) *act_done = 0;
   if (has_act_order) {
     if (is_k_full) {
       NMX_CHECK(num_groups > 1, NMX_ERR_INVALID_ARG, "For act_order, num_groups must be > 1");
@@ -55,6 +58,7 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   else { NMX_DISPATCH_KIND(bf16) }
 #undef NMX_DISPATCH_KIND
   if (splits_out != nullptr) *splits_out = p.k_splits;  // > 1 only when the reduce was deferred to the consumer
+  if (act_done != nullptr) *act_done = p.act_done;
   return rc;
 }
 
@@ -116,6 +120,26 @@ extern "C" int nmx_gptq_marlin_gemm_deferred(const void* a, const int32_t* b_q_w
   return marlin_common(a, b_q_weight, b_scales, g_idx, perm, c, workspace_numel, scratch, scratch_bytes, size_m,
                        size_n, size_k, num_bits == 4 ? W_INT4 : W_INT8, num_groups, is_k_full, dtype,
                        (hipStream_t)stream, 1, splits_out);
+}
+
+// gate_up projection + silu_and_mul as ONE op: act_out [size_m, size_n / 2] = silu(c[:, :size_n/2]) * c[:, size_n/2:] with
+// c = gptq_marlin_gemm(...). Where the dispatch takes the wide-tile kernel without a K split the activation runs in the
+// GEMM's epilogue (one launch, c untouched); everywhere else the deferred GEMM is followed by the consumer launch.
+extern "C" int nmx_gptq_marlin_gemm_silu_and_mul(const void* a, const int32_t* b_q_weight, const void* b_scales,
+                                                 const int32_t* g_idx, const int32_t* perm, void* c, void* act_out,
+                                                 int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int size_m,
+                                                 int size_n, int size_k, int num_bits, int num_groups, int is_k_full,
+                                                 int dtype, nmx_stream_t stream) {
+  NMX_CHECK(num_bits == 4 || num_bits == 8, NMX_ERR_INVALID_ARG, "num_bits must be 4 or 8. Got = %d", num_bits);
+  NMX_CHECK(act_out != nullptr && size_n % 2 == 0 && ((uintptr_t)act_out % 16 == 0) && (size_n / 2) % 8 == 0, NMX_ERR_INVALID_ARG,
+            "gptq_marlin_gemm_silu_and_mul: act_out [size_m, size_n / 2] must be 16-byte aligned, size_n / 2 a multiple of 8");
+  int splits = 1, done = 0;
+  const int rc = marlin_common(a, b_q_weight, b_scales, g_idx, perm, c, workspace_numel, scratch, scratch_bytes, size_m,
+                               size_n, size_k, num_bits == 4 ? W_INT4 : W_INT8, num_groups, is_k_full, dtype,
+                               (hipStream_t)stream, 1, &splits, act_out, &done);
+  if (rc != NMX_OK || done || size_m == 0 || size_n == 0) return rc;
+  if (splits > 1) return nmx_silu_and_mul_splitk(act_out, reinterpret_cast<const float*>(scratch), splits, size_m, size_n / 2, dtype, stream);
+  return nmx_act_and_mul(act_out, c, size_m, size_n / 2, NMX_ACT_SILU, dtype, stream);
 }
 
 extern "C" int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,

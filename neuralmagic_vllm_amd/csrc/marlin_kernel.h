@@ -235,6 +235,9 @@ struct GemmParams {
   int k_splits;
   int slow_act_order;      // act-order with partial K: per-row scale lookup
   int defer_reduce;        // k_splits > 1: leave the fp32 slabs in `partial` for the consumer (no reduce launch)
+  void* act_out = nullptr; // gate_up + silu_and_mul in one launch: [M, N / 2]; the kernels that can do it (marlin_wide,
+                           // no K split) write silu(c[:, :N/2]) * c[:, N/2:] here INSTEAD of c and set act_done
+  int act_done = 0;        // host side only
 };
 
 // ---- the GEMM kernel -------------------------------------------------------------------------------------------
@@ -1180,16 +1183,21 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15, c8 = li & 7, hi = li >> 3;
   const int N = p.N, K = p.K, M = p.M;
-  const int n0 = blockIdx.x * 64;
+  // Fused silu_and_mul (p.act_out; host: no K split, N % 128 == 0, grid.x = N / 128): the lower half of the waves slices K
+  // of gate column group blockIdx.x, the upper half of the up group N / 2 further right - the K slicing and the order of
+  // the sums are those of the plain launch with NW / 2 waves, so the fused op is bit-identical to GEMM + silu_and_mul.
+  const bool fuse_act = p.act_out != nullptr;
+  const int nslice = fuse_act ? NW / 2 : NW;
+  const int n0 = blockIdx.x * 64 + ((fuse_act && wave >= NW / 2) ? N / 2 : 0);
   // row blocks (M > 16 MT) re-read the weights: gridDim.x is a multiple of 8 for every Marlin shape of interest, so
   // the row blocks of one column group have equal workgroup id % 8 = the same XCD and the later one hits its L2
   const int m0 = blockIdx.z * (16 * MT);
 
   // K slice of this wave, in units of 128 k
   const int total_units = K / 128;
-  const int workers = p.k_splits * NW;
+  const int workers = p.k_splits * nslice;
   const int per = (total_units + workers - 1) / workers;
-  const int worker = blockIdx.y * NW + wave;
+  const int worker = blockIdx.y * nslice + (fuse_act ? wave % (NW / 2) : wave);
   const int u0 = min(worker * per, total_units), u1 = min(u0 + per, total_units);
 
   const int row_bytes = N * 8;  // one k-tile row of the packed tensor
@@ -1344,6 +1352,37 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
 #pragma unroll
     for (int t = 0; t < 4; ++t) red[(wave * MT * 4 + mt * 4 + t) * 64 + lane] = acc[mt][t];
   __syncthreads();
+  if (fuse_act) {
+    const int gate0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 256 * MT; e += 64 * NW) {
+      f32x4 sg = red[e], su = red[(NW / 2) * MT * 256 + e];
+#pragma unroll
+      for (int w = 1; w < NW / 2; ++w) {
+        sg += red[w * MT * 256 + e];
+        su += red[(NW / 2 + w) * MT * 256 + e];
+      }
+      const int mt = e >> 8, t = (e >> 6) & 3, el = e & 63, eg = el >> 4;
+      const int m = m0 + mt * 16 + (el & 15);
+      const int col = 32 * (eg >> 1) + 8 * t + 4 * (eg & 1);
+      if (m >= M) continue;
+      if constexpr (!GROUPED) {
+        const scalar_t* sc = reinterpret_cast<const scalar_t*>(p.scales) + gate0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = col + r, cc = c & 7, b = c >> 3;
+          const int pos = 32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3);
+          sg[r] *= Scalar<scalar_t>::to_f32(sc[pos]);
+          su[r] *= Scalar<scalar_t>::to_f32(sc[N / 2 + pos]);
+        }
+      }
+      union { scalar_t h[4]; u32x2 u; } o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        o.h[r] = rnd_mul<scalar_t>(silu_rnd<scalar_t>(Scalar<scalar_t>::from_f32(sg[r])), Scalar<scalar_t>::from_f32(su[r]));
+      *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.act_out) + (int64_t)m * (N / 2) + gate0 + col) = o.u;
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < 256 * MT; e += 64 * NW) {
     f32x4 sum = red[e];
 #pragma unroll
@@ -1638,7 +1677,7 @@ inline DecodeCfg pick_decode_cfg(int M, int N, int K) {
 template <typename scalar_t, int MT, int NW, bool WS>
 int launch_decode_cfg(const GemmParams& p, hipStream_t stream) {
   const size_t smem = (size_t)NW * MT * 4096;
-  dim3 grid(p.N / 64, p.k_splits, ceil_div(p.M, 16 * MT));
+  dim3 grid(p.act_out != nullptr ? p.N / 128 : p.N / 64, p.k_splits, ceil_div(p.M, 16 * MT));
 #define NMX_LAUNCH_DECODE(GROUPED_)                                                                                  \
   {                                                                                                                  \
     auto kern = marlin_decode_kernel<scalar_t, MT, NW, GROUPED_, WS>;                                                    \
@@ -1666,6 +1705,16 @@ int launch_decode(GemmParams& p, const DecodeCfg& cfg, void* scratch, int64_t sc
   // the 16-wave shape exists where it fits 128 registers per lane without spilling: 16 rows, fp16
   constexpr bool HAS16 = __is_same(scalar_t, f16);
   const bool ws = cfg.ws || p.num_groups == 1;
+  // gate_up + silu_and_mul in one launch: the unsplit 4-wave shape run as 4 + 4 waves (gate | up column group)
+  const bool fuse = p.act_out != nullptr && p.k_splits == 1 && cfg.nw == 4 && cfg.mt == 1 && p.N % 128 == 0;
+  void* const act_out = p.act_out;
+  p.act_out = nullptr;  // the kernels below read it as "fused mode"
+  if (fuse) {
+    p.act_out = act_out;
+    rc = ws ? launch_decode_cfg<scalar_t, 1, 8, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 8, false>(p, stream);
+    p.act_done = 1;
+    return rc;
+  }
   if (cfg.mt == 1) {
     if (cfg.nw == 16 && HAS16) {
       if constexpr (HAS16) rc = launch_decode_cfg<scalar_t, 1, 16, true>(p, stream);
@@ -1712,8 +1761,10 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
       call.M = p.M; call.N = p.N; call.K = p.K; call.num_groups = p.num_groups; call.group_size = p.group_size;
       call.kind = KIND; call.is_bf16 = __is_same(scalar_t, bf16) ? 1 : 0;
       call.defer_reduce = p.defer_reduce;
+      call.act_out = p.act_out;
       const int rc = nmx_wide_launch(call, wc, stream);
       p.k_splits = call.splits_done;
+      p.act_done = call.act_done;
       return rc;
     }
     if (use_large(p, false)) return launch_large<scalar_t, KIND>(p, scratch, scratch_bytes, stream);

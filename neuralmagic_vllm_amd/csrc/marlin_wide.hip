@@ -121,7 +121,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   const int tile_x = bx_group * 8 + (bx_r & 7);
   const int block_m = bx_r >> 3;
   if (tile_x * WN * 64 >= N) return;            // padding workgroup (column tiles are rounded up to a multiple of 8)
-  const int n0 = (tile_x * WN + wn) * 64;
+  // Fused silu_and_mul (p.act_out, host guarantees no K split and (N / 2) % (64 WN) == 0): the tile is 32 WN gate columns
+  // PLUS the 32 WN up columns N / 2 further right - column groups wn < WN / 2 stream gate weights, the others the
+  // matching up weights, and the epilogue pairs them through LDS.
+  const bool fuse_act = p.act_out != nullptr;
+  const int n0 = fuse_act ? (wn >= WN / 2 ? N / 2 : 0) + (tile_x * (WN / 2) + (wn % (WN / 2))) * 64 : (tile_x * WN + wn) * 64;
   const bool col_ok = n0 < N;
   const int m0 = block_m * BM;
 
@@ -138,11 +142,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // Every column tile reads the SAME activation rows; workgroups that walk K in the same order hit the same few L2 lines
   // at the same time (28-32 requesters per line and XCD). Each workgroup therefore starts its K walk at its own offset
   // and wraps around: the sum is the same set of products, accumulated in a rotated order.
-  const int n_tiles8 = (N + 64 * WN * 8 - 1) / (64 * WN * 8);
   // The row blocks of one column tile walk in the SAME order: they then stream the tile's weights together and the second
   // one hits L2 (with a per-row-block offset every row block fetched the weights from HBM again: rocprofv3 FETCH_SIZE
   // 150 MB per gate_up launch at M = 256 against 61 MB of operands).
-  const int rot = (NMX_WIDE_ROT && nst > 1) ? (int)(((int64_t)(tile_x >> 3) * nst) / n_tiles8) % nst : 0;
+  // The offset is a function of the PLAIN column tile (64 WN columns), periodic over the two halves of N when they hold whole
+  // tiles: the fused gate | up tile then walks K in the order both of its halves have in the plain launch, and the fused
+  // op stays bit-identical to GEMM + silu_and_mul.
+  const int n_tiles = (N + 64 * WN - 1) / (64 * WN);
+  const int period = (N % (128 * WN) == 0) ? n_tiles / 2 : n_tiles;
+  const int tile_plain = fuse_act ? tile_x >> 1 : tile_x;
+  const int rot = (NMX_WIDE_ROT && nst > 1) ? (int)(((int64_t)(tile_plain % period) * nst) / period) % nst : 0;
   auto stage_of = [&](int rel) {                 // absolute stage of this slice's rel-th iteration (clamped past the end)
     int r = min(rel, max(nst - 1, 0)) + rot;
     r = r >= nst ? r - nst : r;
@@ -481,6 +490,41 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       }
     }
   }
+  if (fuse_act) {
+    // silu_and_mul on the fp16 / bf16 ROUNDED gate and up values, the arithmetic of act_and_mul_kernel (elementwise.hip;
+    // reference activation_kernels.cu:12-30): out = scalar_t(silu(float(gate))) * up, rounded once more
+    constexpr int HW = WN / 2;
+    u32x2* ex = reinterpret_cast<u32x2*>(smem);
+    __syncthreads();  // stage buffers / reduction slabs are free
+    const int pair = (wm * HW + wn % HW) * (MT * NTILE * 64);
+    if (wk == 0 && wn >= HW) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
+          ex[pair + (mt * NTILE + t) * 64 + lane] = r.u;
+        }
+    }
+    __syncthreads();
+    if (wk != 0 || wn >= HW || !col_ok) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + wm * 16 * MT + mt * 16 + li;
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        union { scalar_t h[4]; u32x2 u; } up, o;
+        up.u = ex[pair + (mt * NTILE + t) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.h[j] = rnd_mul<scalar_t>(silu_rnd<scalar_t>(Scalar<scalar_t>::from_f32(acc[mt][t][j])), up.h[j]);
+        const int n = n0 + 32 * (g >> 1) + 8 * t + 4 * (g & 1);
+        if (m < M) *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.act_out) + (int64_t)m * (N / 2) + n) = o.u;
+      }
+    }
+    return;
+  }
   if (wk != 0 || !col_ok) return;
 
   // lane (g, li): D rows = 4 consecutive output columns 32 (g >> 1) + 8 t + 4 (g & 1) + r, D col = activation row li
@@ -508,7 +552,8 @@ int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM;
   const size_t stage = (size_t)WK * 2 * BM * 128;
   const size_t red = (WK > 1) ? (size_t)(WK / 2) * WM * WN * MT * 4 * 64 * 4 * sizeof(float) : 0;
-  const size_t smem = std::max(stage, red);
+  const size_t ex = (size_t)WM * (WN / 2) * MT * 4 * 64 * 8;  // fused silu_and_mul: the up halves as fp16 / bf16
+  const size_t smem = std::max(std::max(stage, red), ex);
   dim3 grid(ceil_div(ceil_div(p.N, 64 * WN), 8) * 8 * ceil_div(p.M, BM), p.k_splits, 1);
   auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK, MT>;
   if (smem > 64 * 1024)
@@ -617,6 +662,9 @@ int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream
   p.slow_act_order = 0;
   p.defer_reduce = call.defer_reduce;
   p.k_splits = cfg.splits;
+  // fused silu_and_mul epilogue: only a launch whose workgroups own whole K (the slabs of a K split belong to the consumer)
+  call.act_done = (call.act_out != nullptr && cfg.splits == 1 && call.N % 2 == 0 && (call.N / 2) % (64 * cfg.wn) == 0) ? 1 : 0;
+  p.act_out = call.act_done ? call.act_out : nullptr;
   if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to the splits that fit
     const int64_t per = (int64_t)p.M * p.N * sizeof(float);
     const int fit = call.scratch == nullptr ? 1 : (int)std::min<int64_t>(p.k_splits, call.scratch_bytes / per);

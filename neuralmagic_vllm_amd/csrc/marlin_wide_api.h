@@ -17,6 +17,8 @@ struct NmxWideCall {
   int is_bf16;
   int defer_reduce;       // leave split-K partials in scratch (no reduce launch)
   int splits_done;        // out: K splits the launch used
+  void* act_out = nullptr;  // [M, N / 2]: fuse silu_and_mul into the epilogue when the launch has no K split (see act_done)
+  int act_done = 0;         // out: act_out was written (and c was not)
 };
 
 // tile configuration of marlin_wide_kernel: wm x wn x wk waves, `splits` K splits across workgroups

@@ -73,6 +73,15 @@ template <> struct Scalar<bf16> {
   static __device__ __forceinline__ bf16 from_f32(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
 };
 
+template <typename T> __device__ __forceinline__ T rnd_mul(T a, T b) {  // scalar_t * scalar_t -> scalar_t
+  return Scalar<T>::from_f32(Scalar<T>::to_f32(a) * Scalar<T>::to_f32(b));
+}
+// silu in the reference's arithmetic (activation_kernels.cu:27-30): float math, result rounded to scalar_t
+template <typename T> __device__ __forceinline__ T silu_rnd(T xv) {
+  const float f = Scalar<T>::to_f32(xv);
+  return Scalar<T>::from_f32(f / (1.0f + expf(-f)));
+}
+
 // fp8 (OCP) byte -> float
 __device__ __forceinline__ float fp8_e4m3_to_f32(uint8_t v) {
   return __builtin_amdgcn_cvt_f32_fp8((uint32_t)v, 0);

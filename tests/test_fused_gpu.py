@@ -77,6 +77,54 @@ def test_deferred_gemm_silu_and_mul(ops, M):
     torch.testing.assert_close(out_b.cpu().float(), out_o.float(), atol=2e-3, rtol=2e-3)
 
 
+def _gate_up_case(ops, M, K, N, dtype, grouped, seed):
+    """(two-op result, one-op result) of silu_and_mul(gptq_marlin_gemm(a, w)) on the same operands"""
+    seed_all(seed)
+    q, s = _weights(K, N, seed)
+    if not grouped:
+        s = s[:1].contiguous()
+    s = s.to(dtype)
+    a = torch.randn(M, K, dtype=dtype, device=DEV)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
+    plain = ops.gptq_marlin_gemm(a, q, s, e, e, ws, 4, M, N, K, True)
+    two = torch.empty(M, N // 2, dtype=dtype, device=DEV)
+    ops.silu_and_mul(two, plain)
+    one = ops.gptq_marlin_gemm_silu_and_mul(a, q, s, e, e, ws, 4, M, N, K, True)
+    torch.cuda.synchronize()
+    return plain, two, one
+
+
+@pytest.mark.parametrize("M", [1, 5, 8, 16, 33, 64, 100, 128, 256, 300])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gate_up_gemm_silu_and_mul(ops, M, dtype):
+    """gate_up projection + silu_and_mul as one op on the Llama-3-8B shape, default dispatch: M in (32, 256] takes the
+    wide-tile kernel without a K split = the activation runs in the GEMM epilogue; the other sizes take GEMM + consumer.
+    Bit-identical to the two ops, and the oracle's silu_and_mul of the same GEMM output to rounding."""
+    K, N = 4096, 28672
+    plain, two, one = _gate_up_case(ops, M, K, N, dtype, True, M)
+    assert torch.equal(_bits(two), _bits(one))
+    out_o = torch.empty(M, N // 2, dtype=dtype)
+    oracle.act_and_mul(out_o, plain.cpu(), "silu")
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    torch.testing.assert_close(one.cpu().float(), out_o.float(), atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("wide", ["1,4,1", "1,2,1", "2,2,1", "2,4,1", "1,2,1,4", "1,4,1,4", "1,4,2"])
+@pytest.mark.parametrize("grouped", [True, False])
+def test_gate_up_gemm_silu_and_mul_tiles(ops, tune, wide, grouped):
+    """every tile shape of the wide kernel with the fused epilogue (forced through NMX_GEMM_WIDE; "1,4,2" splits K and must
+    fall back to GEMM + consumer), ragged M, a column count that leaves padding workgroups"""
+    K, N = 1024, 2 * 1280
+    M = 50 if wide.endswith(",4") else 200
+    tune(NMX_GEMM_WIDE=None)
+    ref = _gate_up_case(ops, M, K, N, torch.float16, grouped, 11)[1]
+    tune(NMX_GEMM_WIDE=wide)
+    _, two, one = _gate_up_case(ops, M, K, N, torch.float16, grouped, 11)
+    assert torch.equal(_bits(two), _bits(one))
+    torch.testing.assert_close(one.float(), ref.float(), atol=2e-3, rtol=2e-3)  # other tile shape: another summation order
+
+
 @pytest.mark.parametrize("M", [1, 7, 16, 64, 200])
 @pytest.mark.parametrize("kv_dtype", ["auto", "fp8"])
 @pytest.mark.parametrize("deferred", [True, False])
