@@ -29,6 +29,9 @@ namespace {
 #ifndef NMX_WIDE_ROT
 #define NMX_WIDE_ROT 1   // rotate every workgroup's K order (see stage_of)
 #endif
+#ifndef NMX_WIDE_RING
+#define NMX_WIDE_RING(MT) ((MT) == 4 ? 8 : 4)   // weight ring slots (k-steps) of the 64-row / 128-row wave tiles
+#endif
 #ifndef NMX_WIDE_NT
 #define NMX_WIDE_NT 0    // non-temporal weight loads
 #endif
@@ -188,13 +191,18 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   const int s_voff = (int)((((col_ok ? n0 : 0) / 64) * 64 + 8 * c8 + 4 * hi) * sizeof(scalar_t));
 
   struct BStep { bvec_t q0, q1; };
-  BStep ring[4];                                 // k-step j of this slice lives in ring[j & 3]
+  // k-step j of this slice lives in ring[j % RD]. 128-row wave tiles: 4 slots (2 stages ahead; the registers are the
+  // accumulators'). 64-row wave tiles have registers to spare and run where the weight stream is the bound (M <= 64 ...
+  // 256 on small matrices): 8 slots = 7 k-steps (7 KiB per wave, 56 KiB per CU) of weights in flight - tools/probes/
+  // l2_ingest_probe.hip needs ~64 KiB per CU to saturate HBM.
+  constexpr int RD = NMX_WIDE_RING(MT);
+  BStep ring[RD];
   u32x4 areg[NA];
   u32x2 sraw = {0, 0};
   u32x2 scc = {0, 0}, scn = {0, 0};              // packed scale rows (4 halves = the lane's 4 tiles) of the current / next stage
   WFrag wfa, wfb;                                // dequantised fragments of the even / odd k-step of a stage
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ring[i].q0 = bvec_t{}; ring[i].q1 = bvec_t{}; }
+  for (int i = 0; i < RD; ++i) { ring[i].q0 = bvec_t{}; ring[i].q1 = bvec_t{}; }
 #pragma unroll
   for (int i = 0; i < NA; ++i) areg[i] = u32x4{0, 0, 0, 0};
 
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         constexpr int STEP = MT / NA;
         if (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
         if (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
-        if (mt == 1) issue_w(2 * st + 5, refill);
+        if (mt == 1) issue_w(2 * st + 1 + RD, refill);
       }
     }
     if constexpr (LAND) load_piece(NA - 1, st + 2);
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         constexpr int STEP = MT / NA;
         if constexpr (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
         if constexpr (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
-        if constexpr (mt == 1) issue_w(2 * st + 5, refill);
+        if constexpr (mt == 1) issue_w(2 * st + 1 + RD, refill);
       }
     };
     row(std::integral_constant<int, 0>{});
@@ -390,17 +398,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   if constexpr (SCALED) scc = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(0), 0);
   issue_w(0, ring[0]);
   issue_batch(0);
-  issue_w(1, ring[1]);
-  issue_w(2, ring[2]);
+#pragma unroll
+  for (int j = 1; j <= RD - 2; ++j) issue_w(j, ring[j]);
 #pragma unroll
   for (int i = 0; i < NA; ++i) write_piece(i, 0);
   scn = sraw;
   dequant_cxx(ring[0], scc, wfa);
   // the same order as an iteration issues them: hipcc merges the pending-load state of this path and of the loop's back
   // edge at the loop head, and any difference turns the first waits of the body into vmcnt(0)
-  issue_w(3, ring[3]);
+  issue_w(RD - 1, ring[RD - 1]);
   issue_batch(1);
-  issue_w(4, ring[0]);
+  issue_w(RD, ring[0]);
   stage_barrier();
 
   using KS0 = std::integral_constant<int, 0>;
@@ -408,10 +416,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   using NOLAND = std::integral_constant<bool, false>;
   using DOLAND = std::integral_constant<bool, true>;
   auto body = [&](auto par_c, int it) {
-    constexpr int PAR = decltype(par_c)::value;   // = it & 1: LDS buffer, and ring slots 2 PAR + {1, 2}
+    constexpr int PH = decltype(par_c)::value;    // = it % (RD / 2): ring slots 2 PH + {1, 2}
+    constexpr int PAR = PH & 1;                   // LDS buffer
     const int st = it;  // relative stage of the walk
-    BStep& r1 = ring[(2 * PAR + 1) & 3];
-    BStep& r2 = ring[(2 * PAR + 2) & 3];
+    BStep& r1 = ring[(2 * PH + 1) % RD];
+    BStep& r2 = ring[(2 * PH + 2) % RD];
     u32x4 af[MT + 4];  // 0..7: k-step 0, 8..11: first four of k-step 1 (then 4..7 again)
     if constexpr ((NMX_WABLATE & 4) == 0) {
 #pragma unroll
@@ -434,15 +443,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     scc = scn;
     scn = sraw;
     load_scale(st + 2);
-    issue_w(2 * st + 6, r2);
+    issue_w(2 * st + 2 + RD, r2);
     stage_barrier();
   };
   // Always whole pairs of iterations (an odd `per` runs one more, on zero activations): with a conditional second half
   // there is a control-flow path from body 0 straight back to body 0, and hipcc's wait counts at the loop head then
   // assume that order of pending loads too (vmcnt(1) / vmcnt(0) in front of the first k-step's conversion).
-  for (int it = 0; it < per; it += 2) {
+  // (8 slots: whole quadruples - a ring slot index must be a compile-time constant, registers cannot be indexed)
+  for (int it = 0; it < per; it += RD / 2) {
     body(std::integral_constant<int, 0>{}, it);
     body(std::integral_constant<int, 1>{}, it + 1);
+    if constexpr (RD == 8) {
+      body(std::integral_constant<int, 2>{}, it + 2);
+      body(std::integral_constant<int, 3>{}, it + 3);
+    }
   }
   // the s_nop covers the MFMA -> VALU read distance that hipcc does not know about (the MFMAs are asm statements)
 #pragma unroll
