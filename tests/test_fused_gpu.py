@@ -95,7 +95,7 @@ def _gate_up_case(ops, M, K, N, dtype, grouped, seed):
     return plain, two, one
 
 
-@pytest.mark.parametrize("M", [1, 5, 8, 16, 33, 64, 100, 128, 256, 300])
+@pytest.mark.parametrize("M", [1, 5, 8, 12, 16, 24, 32, 33, 64, 100, 128, 256, 300])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gate_up_gemm_silu_and_mul(ops, M, dtype):
     """gate_up projection + silu_and_mul as one op on the Llama-3-8B shape, default dispatch: M in (32, 256] takes the
