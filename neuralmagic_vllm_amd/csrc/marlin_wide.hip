@@ -212,8 +212,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue_w = [&](int kstep_rel, BStep& r) {  // k-step 2 rel + ks of this slice's walk
-    const int soff = 2 * (2 * stage_of(kstep_rel >> 1) + (kstep_rel & 1)) * row_bytes;  // never past the tensor
+  // The loads below take ABSOLUTE stages. The prologue gets them from stage_of(); the main loop keeps the stages of the
+  // walk positions it will need next in SGPRs (wpos[], advanced once per iteration by walk_advance) - stage_of() per load
+  // was 29 scalar instructions per k-step, a quarter of the loop's instruction stream at 64 rows.
+  auto issue_w = [&](int stage, int ks, BStep& r) {  // k-step ks of absolute stage `stage`
+    const int soff = 2 * (2 * stage + ks) * row_bytes;  // never past the tensor
     if constexpr ((NMX_WABLATE & 64) != 0) return;
     if constexpr (I4) {
       r.q0 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff, NMX_WIDE_NT ? 2 : 0);
@@ -223,24 +226,42 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       r.q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff + row_bytes, NMX_WIDE_NT ? 2 : 0);
     }
   };
-  auto scale_soff = [&](int rel) {
-    const int grp = min((stage_of(rel) * 64) / p.group_size, p.num_groups - 1);
+  // group of a stage = stage / (group_size / 64) as a multiply-high with the rounded-up reciprocal of 2^31 (branch-free, also
+  // for one stage per group; exact while stage * stages_per_group < 2^31)
+  const uint32_t gs_stages = SCALED ? (uint32_t)max(p.group_size / 64, 1) : 1u;
+  const uint32_t gs_inv = (0x80000000u + gs_stages - 1) / gs_stages;
+  auto scale_soff = [&](int stage) {
+    const int grp = min((int)__umulhi(2u * (uint32_t)stage, gs_inv), p.num_groups - 1);
     return grp * N * (int)sizeof(scalar_t);
   };
   // batch(rel): the activation pieces of the rel-th stage of the walk and the scale row of stage rel + 1
-  auto load_piece = [&](int i, int st) {  // activation piece i of the st-th stage of the walk
+  auto load_piece = [&](int i, int stage, bool in_range) {  // activation piece i of absolute stage `stage`
     if constexpr ((NMX_WABLATE & 32) != 0) return;
-    const int soff = stage_of(st) * 64 * (int)sizeof(scalar_t);
-    const int lim = st < nst ? a_lim : 0;
+    const int soff = stage * 64 * (int)sizeof(scalar_t);
+    const int lim = in_range ? a_lim : 0;
     areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, i * (TS / 8) < lim ? a_base : (int)0x7ff00000, soff + i * a_step, 0);
   };
-  auto load_scale = [&](int st) {
-    if constexpr (SCALED) sraw = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(st + 1), 0);
+  auto load_scale = [&](int stage) {  // the scale row of absolute stage `stage`
+    if constexpr (SCALED) sraw = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(stage), 0);
   };
-  auto issue_batch = [&](int st) {
+  auto issue_batch = [&](int st) {  // prologue: walk position st
 #pragma unroll
-    for (int i = 0; i < NA; ++i) load_piece(i, st);
-    load_scale(st);
+    for (int i = 0; i < NA; ++i) load_piece(i, stage_of(st), st < nst);
+    load_scale(stage_of(st + 1));
+  };
+  // walk positions st + 2 .. st + 1 + RD / 2 of the iteration that runs stage st (wpos[0]: its activation batch, wpos[1]: its
+  // scale row, wpos[RD / 2 - 2], wpos[RD / 2 - 1]: its two weight k-steps)
+  constexpr int NCUR = RD / 2;
+  int wpos[NCUR];
+#pragma unroll
+  for (int j = 0; j < NCUR; ++j) wpos[j] = stage_of(2 + j);
+  auto walk_advance = [&](int st) {  // after the iteration of stage st: positions st + 3 .. st + 2 + RD / 2
+    int nx = wpos[NCUR - 1] + 1;
+    nx = nx >= st_begin + nst ? st_begin : nx;
+    nx = st + 2 + NCUR < nst ? nx : wpos[NCUR - 1];  // past the end of the slice: stay on its last stage (never consumed)
+#pragma unroll
+    for (int j = 0; j + 1 < NCUR; ++j) wpos[j] = wpos[j + 1];
+    wpos[NCUR - 1] = nx;
   };
   auto scale_operand = [&](u32x2 v, int t) -> uint32_t {  // what Dequant<>::run expects: (s, s) fp16 pair / fp32 bits
     union { u32x2 v; scalar_t e[4]; } raw;
@@ -330,11 +351,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       if constexpr (LAND) {
         constexpr int STEP = MT / NA;
         if (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
-        if (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
-        if (mt == 1) issue_w(2 * st + 1 + RD, refill);
+        if (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, wpos[0], st + 2 < nst);
+        if (mt == 1) issue_w(wpos[NCUR - 2], 1, refill);  // k-step 2 st + 1 + RD
       }
     }
-    if constexpr (LAND) load_piece(NA - 1, st + 2);
+    if constexpr (LAND) load_piece(NA - 1, wpos[0], st + 2 < nst);
   };
   // FAST path: the same block with the conversion operations placed two per MFMA
   auto kstep_block_fast = [&](auto ks_c, auto land_c, const WFrag& cur, const BStep& nxt, const u32x2& s2, WFrag& out,
@@ -377,8 +398,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       if constexpr (LAND) {  // see kstep_block
         constexpr int STEP = MT / NA;
         if constexpr (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
-        if constexpr (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, st + 2);
-        if constexpr (mt == 1) issue_w(2 * st + 1 + RD, refill);
+        if constexpr (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, wpos[0], st + 2 < nst);
+        if constexpr (mt == 1) issue_w(wpos[NCUR - 2], 1, refill);  // k-step 2 st + 1 + RD
       }
     };
     row(std::integral_constant<int, 0>{});
@@ -391,24 +412,24 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       row(std::integral_constant<int, 6>{});
       row(std::integral_constant<int, 7>{});
     }
-    if constexpr (LAND) load_piece(NA - 1, st + 2);
+    if constexpr (LAND) load_piece(NA - 1, wpos[0], st + 2 < nst);
   };
 
   // ---- prologue, in the steady-state issue order ----
-  if constexpr (SCALED) scc = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(0), 0);
-  issue_w(0, ring[0]);
+  if constexpr (SCALED) scc = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(stage_of(0)), 0);
+  issue_w(stage_of(0), 0, ring[0]);
   issue_batch(0);
 #pragma unroll
-  for (int j = 1; j <= RD - 2; ++j) issue_w(j, ring[j]);
+  for (int j = 1; j <= RD - 2; ++j) issue_w(stage_of(j >> 1), j & 1, ring[j]);
 #pragma unroll
   for (int i = 0; i < NA; ++i) write_piece(i, 0);
   scn = sraw;
   dequant_cxx(ring[0], scc, wfa);
   // the same order as an iteration issues them: hipcc merges the pending-load state of this path and of the loop's back
   // edge at the loop head, and any difference turns the first waits of the body into vmcnt(0)
-  issue_w(RD - 1, ring[RD - 1]);
+  issue_w(stage_of((RD - 1) >> 1), 1, ring[RD - 1]);
   issue_batch(1);
-  issue_w(RD, ring[0]);
+  issue_w(stage_of(RD >> 1), 0, ring[0]);
   stage_barrier();
 
   using KS0 = std::integral_constant<int, 0>;
@@ -442,8 +463,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     }
     scc = scn;
     scn = sraw;
-    load_scale(st + 2);
-    issue_w(2 * st + 2 + RD, r2);
+    load_scale(wpos[1]);               // scale row of walk position st + 3
+    issue_w(wpos[NCUR - 1], 0, r2);    // k-step 2 st + 2 + RD
+    walk_advance(st);
     stage_barrier();
   };
   // Always whole pairs of iterations (an odd `per` runs one more, on zero activations): with a conditional second half

@@ -201,3 +201,16 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         if bias is not None:
             output.add_(bias)
         return output.reshape(out_shape)
+
+    def apply_silu_and_mul(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+        """SiluAndMul(apply(layer, x)) for a merged gate | up projection without bias as ONE op (extension; the reference's
+        LlamaMLP.forward runs gate_up_proj, then act_fn: models/llama.py:79-83). Same values as the two calls."""
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        if layer.marlin_state == GPTQMarlinState.REPACK:
+            layer.marlin_state = GPTQMarlinState.READY
+            self._repack(layer)
+        act = ops.gptq_marlin_gemm_silu_and_mul(reshaped_x, layer.qweight, layer.scales, layer.g_idx, layer.g_idx_sort_indices,
+                                                layer.workspace, self.quant_config.weight_bits, reshaped_x.shape[0],
+                                                layer.output_size_per_partition, layer.input_size_per_partition,
+                                                layer.is_k_full)
+        return act.reshape(x.shape[:-1] + (layer.output_size_per_partition // 2, ))

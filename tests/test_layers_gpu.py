@@ -56,6 +56,13 @@ def test_gptq_marlin_method(bits, group, desc_act, m):
     assert compute_max_diff(out.cpu(), ref) < 1e-3
     out2 = method.apply(layer, x.to(DEV), bias.to(DEV))  # second call: no repack
     assert torch.equal(out, out2)
+    # merged gate | up projection + SiluAndMul as one op (extension): the same values as the two calls
+    from neuralmagic_vllm_amd import _custom_ops as ops
+    gate_up = method.apply(layer, x.to(DEV))
+    two = torch.empty(3, m, N // 2, dtype=torch.float16, device=DEV)
+    ops.silu_and_mul(two, gate_up)
+    one = method.apply_silu_and_mul(layer, x.to(DEV))
+    assert one.shape == two.shape and torch.equal(one, two)
 
 
 def test_marlin_checkpoint_method():
