@@ -18,7 +18,7 @@ ks = " ".join(f"{n}={v['us']}" for n, v in k.items())
 print(f"{sys.argv[1]:24} batch {int(sys.argv[2]):4d}  {r['value']:9.1f} tok/s  {r['ms_per_step']:7.3f} ms  frac={r['roofline']['frac']:.3f}  {ks}")
 PY
 }
-for b in 1 8 32 64 128 256; do run int4 $b; done
+for b in 1 8 16 32 64 128 256; do run int4 $b; done
 for b in 1 64 256; do run int4 $b --no-fuse; done
 for b in 64 256; do run sparse24 $b; done
 for b in 64 256; do run fp8 $b; done
