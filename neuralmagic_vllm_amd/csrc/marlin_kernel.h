@@ -238,6 +238,7 @@ struct GemmParams {
   void* act_out = nullptr; // gate_up + silu_and_mul in one launch: [M, N / 2]; the kernels that can do it (marlin_wide,
                            // no K split) write silu(c[:, :N/2]) * c[:, N/2:] here INSTEAD of c and set act_done
   int act_done = 0;        // host side only
+  int xcd_split = 1;       // marlin_gemm_kernel: 2 / 4 / 8 K splits are placed one per group of XCDs (NMX_GEMM_XCD_SPLIT=0: off)
 };
 
 // ---- the GEMM kernel -------------------------------------------------------------------------------------------
@@ -298,9 +299,24 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   // apart: consecutive ids go to consecutive XCDs, so they land on the SAME XCD a few dispatches apart and the second
   // row block finds the tile's weights in that XCD's L2 instead of fetching them from HBM again.
   const int m_blocks = (p.M + ROWS - 1) / ROWS;
-  const int bx_group = blockIdx.x / (8 * m_blocks), bx_r = blockIdx.x % (8 * m_blocks);
-  const int tile_x = bx_group * 8 + (bx_r & 7);
-  const int block_m = bx_r >> 3;
+  // With 2 / 4 / 8 K splits the XCD (= linear workgroup id % 8; gridDim.x is a multiple of 8) selects the K SPLIT as well:
+  // 8 / splits XCDs share one split, each of them a disjoint set of column tiles. A split's slice of the ACTIVATIONS is then
+  // fetched by 8 / splits XCDs instead of all 8 (down_proj at M = 256: 7.3 MB of activations were fetched 8 x = 59 of the
+  // launch's 101 MB), the weights of a (tile, split) stay with one XCD as before.
+  int tile_x, block_m, split_id;
+  if (p.xcd_split && (p.k_splits == 2 || p.k_splits == 4 || p.k_splits == 8)) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int per = 8 / p.k_splits;  // XCDs per split
+    const int q = lin >> 3;
+    split_id = (lin & 7) / per;
+    block_m = q % m_blocks;
+    tile_x = (q / m_blocks) * per + (lin & 7) % per;
+  } else {
+    const int bx_group = blockIdx.x / (8 * m_blocks), bx_r = blockIdx.x % (8 * m_blocks);
+    tile_x = bx_group * 8 + (bx_r & 7);
+    block_m = bx_r >> 3;
+    split_id = blockIdx.y;
+  }
   if (tile_x * NG * 64 >= p.N) return;      // padding workgroup (column tiles are rounded up to a multiple of 8)
   // this wave's 64-column group. Fused silu_and_mul (p.act_out; host: NG >= 2, no K split, (N / 2) % (32 NG) == 0): the tile
   // is 32 NG gate columns plus the 32 NG up columns N / 2 further right (column groups ng >= NG / 2), paired in the epilogue.
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   const int total_sub = (total_steps + SUB - 1) / SUB;
   const int nworkers = p.k_splits * KW;
   const int sub_per = (total_sub + nworkers - 1) / nworkers;
-  const int worker = blockIdx.y * KW + kslice;
+  const int worker = split_id * KW + kslice;
   const int sub_begin = min(worker * sub_per, total_sub);
   const int sub_end = min(sub_begin + sub_per, total_sub);
   // all K-slices of a workgroup run the same number of iterations (barriers): the longest one
@@ -969,7 +985,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
             o.h[1] = Scalar<scalar_t>::from_f32(v1);
             *reinterpret_cast<uint32_t*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = o.u;
           } else {
-            *reinterpret_cast<f32x2*>(p.partial + ((int64_t)blockIdx.y * M + m) * N + n) = f32x2{v0, v1};
+            *reinterpret_cast<f32x2*>(p.partial + ((int64_t)split_id * M + m) * N + n) = f32x2{v0, v1};
           }
         }
       }
@@ -990,7 +1006,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
         for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
         *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = r.u;
       } else {
-        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * M + m) * N + n) = acc[mt][t];
+        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
       }
     }
   }
@@ -1819,6 +1835,7 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
     }
   }
   p.partial = reinterpret_cast<float*>(scratch);
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_XCD_SPLIT)) p.xcd_split = atoi(e) != 0;
   int rc;
   const int sub_k = (KIND == W_INT4) ? 128 : 64;
   const bool generic = p.perm != nullptr || p.slow_act_order || (p.num_groups > 1 && p.group_size % 128 != 0) ||
