@@ -120,9 +120,22 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // blockIdx.x -> (column tile, row block); the row blocks of one column tile are 8 ids apart = same XCD (placement is
   // a speed matter only: the second row block then finds the tile's weights in that XCD's L2)
   const int m_blocks = (M + BM - 1) / BM;
-  const int bx_group = blockIdx.x / (8 * m_blocks), bx_r = blockIdx.x % (8 * m_blocks);
-  const int tile_x = bx_group * 8 + (bx_r & 7);
-  const int block_m = bx_r >> 3;
+  // With 2 / 4 / 8 K splits the XCD (= linear workgroup id % 8) selects the split too, as in marlin_gemm_kernel: a split's
+  // slice of the activations is then fetched by 8 / splits XCDs instead of all 8.
+  int tile_x, block_m, split_id;
+  if (p.xcd_split && (p.k_splits == 2 || p.k_splits == 4 || p.k_splits == 8)) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int per_split = 8 / p.k_splits;
+    const int q = lin >> 3;
+    split_id = (lin & 7) / per_split;
+    block_m = q % m_blocks;
+    tile_x = (q / m_blocks) * per_split + (lin & 7) % per_split;
+  } else {
+    const int bx_group = blockIdx.x / (8 * m_blocks), bx_r = blockIdx.x % (8 * m_blocks);
+    tile_x = bx_group * 8 + (bx_r & 7);
+    block_m = bx_r >> 3;
+    split_id = blockIdx.y;
+  }
   if (tile_x * WN * 64 >= N) return;            // padding workgroup (column tiles are rounded up to a multiple of 8)
   // Fused silu_and_mul (p.act_out, host guarantees no K split and (N / 2) % (64 WN) == 0): the tile is 32 WN gate columns
   // PLUS the 32 WN up columns N / 2 further right - column groups wn < WN / 2 stream gate weights, the others the
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   const int total_stages = K / 64;
   const int workers = p.k_splits * WK;
   const int per = (total_stages + workers - 1) / workers;
-  const int worker = blockIdx.y * WK + wk;
+  const int worker = split_id * WK + wk;
   const int st_begin = min(worker * per, total_stages), st_end = min(st_begin + per, total_stages);
   const int nst = st_end - st_begin;             // stages this slice really has (the rest of `per` multiply zeros)
   // Every column tile reads the SAME activation rows; workgroups that walk K in the same order hit the same few L2 lines
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
         *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = r.u;
       } else {
-        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)blockIdx.y * M + m) * N + n) = acc[mt][t];
+        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
       }
     }
   }
@@ -696,6 +709,7 @@ int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream
   p.a = call.a; p.b = call.b; p.meta = nullptr; p.zeros = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
   p.M = call.M; p.N = call.N; p.K = call.K; p.num_groups = call.num_groups; p.group_size = call.group_size;
   p.slow_act_order = 0;
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_XCD_SPLIT)) p.xcd_split = atoi(e) != 0;
   p.defer_reduce = call.defer_reduce;
   p.k_splits = cfg.splits;
   // fused silu_and_mul epilogue: only a launch whose workgroups own whole K (the slabs of a K split belong to the consumer)
