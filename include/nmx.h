@@ -155,6 +155,9 @@ int nmx_gptq_marlin_gemm_deferred(const void* a, const int32_t* b_q_weight, cons
                                   const int32_t* perm, void* c, int64_t workspace_numel, void* scratch,
                                   int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits,
                                   int num_groups, int is_k_full, int dtype, int* splits_out, nmx_stream_t stream);
+/* out [size_m, size_n] = scalar_t(sum_s partial[s]), s = 0, 1, ... : the split-K reduce launch as an op, for consumers of a
+ * deferred GEMM without a fused form (same bits as the plain GEMM's output). */
+int nmx_splitk_reduce(void* out, const float* partial, int splits, int size_m, int size_n, int dtype, nmx_stream_t stream);
 /* gate_up projection + silu_and_mul as one op (LlamaMLP.forward, vllm/model_executor/models/llama.py:79-83: gate_up_proj
  * then SiluAndMul): act_out [size_m, size_n / 2] = silu(c[:, :size_n/2]) * c[:, size_n/2:], c = gptq_marlin_gemm(...), both
  * roundings of the two-op sequence kept (bit-identical). One launch where the dispatch takes the wide-tile kernel without a

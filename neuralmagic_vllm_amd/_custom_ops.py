@@ -507,10 +507,12 @@ class DeferredGemm:
     def materialize(self) -> torch.Tensor:
         """Plain reduction (what the reduce launch would have produced), for consumers without a fused form."""
         if self.splits > 1:
-            acc = self.partial.sum(dim=0)
-            if self.sa is not None:
-                acc = self.sa * (self.sb * acc)
-            self.out.copy_(acc)
+            if self.sa is not None:  # fp8 scaled_mm: the scale epilogue belongs to the reduction
+                self.out.copy_(self.sa * (self.sb * self.partial.sum(dim=0)))
+            else:  # the GEMMs' own reduce kernel: slabs summed in the order s = 0, 1, ... like the plain op
+                m, n = self.out.shape
+                _lib.check(_lib.lib().nmx_splitk_reduce(_p(self.out), _p(self.partial), c_int(self.splits), c_int(m), c_int(n),
+                                                        c_int(_dt(self.out)), _stream(self.out)))
             self.splits = 1
         return self.out
 

@@ -142,6 +142,24 @@ extern "C" int nmx_gptq_marlin_gemm_silu_and_mul(const void* a, const int32_t* b
   return nmx_act_and_mul(act_out, c, size_m, size_n / 2, NMX_ACT_SILU, dtype, stream);
 }
 
+// out [m, n] = scalar_t(sum_s partial[s]) in the order s = 0, 1, ...: the reduce launch of the split-K GEMMs as an op of its
+// own, for consumers of a deferred GEMM that have no fused form (bit-identical to the plain GEMM's output)
+extern "C" int nmx_splitk_reduce(void* out, const float* partial, int splits, int size_m, int size_n, int dtype,
+                                 nmx_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "splitk_reduce: fp16 / bf16 only");
+  NMX_CHECK(splits >= 1 && size_n % 4 == 0 && ((uintptr_t)out % 8 == 0) && ((uintptr_t)partial % 16 == 0), NMX_ERR_INVALID_ARG,
+            "splitk_reduce: size_n %% 4 == 0, out 8-byte and partial 16-byte aligned");
+  const int64_t mn4 = (int64_t)size_m * size_n / 4;
+  if (mn4 == 0) return NMX_OK;
+  if (dtype == NMX_F16)
+    splitk_reduce_kernel<f16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<f16*>(out), partial, mn4, splits);
+  else
+    splitk_reduce_kernel<bf16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<bf16*>(out), partial, mn4, splits);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
 extern "C" int nmx_marlin_gemm(const void* a, const int32_t* b_q_weight, const void* b_scales, void* c,
                                int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int size_m,
                                int size_n, int size_k, int num_groups, nmx_stream_t stream) {

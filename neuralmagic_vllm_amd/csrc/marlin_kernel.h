@@ -1428,6 +1428,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
           const int pos = 32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3);
           sg[r] *= Scalar<scalar_t>::to_f32(sc[pos]);
           su[r] *= Scalar<scalar_t>::to_f32(sc[N / 2 + pos]);
+          asm volatile("" : "+v"(sg[r]), "+v"(su[r]));  // see the plain epilogue below
         }
       }
       union { scalar_t h[4]; u32x2 u; } o;
@@ -1454,6 +1455,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
       for (int r = 0; r < 4; ++r) {
         const int c = col + r, cc = c & 7, b = c >> 3;
         sum[r] *= Scalar<scalar_t>::to_f32(sc[32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3)]);
+        // keep the fp32 product a value of its own: hipcc otherwise fuses this multiply with the fp16 conversion below
+        // (v_fma_mixlo_f16, ONE rounding) here but not in the fused epilogue above, where the rounded value is used again
+        // as a float - the two forms of the op must round alike
+        asm volatile("" : "+v"(sum[r]));
       }
     }
     if (p.k_splits == 1) {

@@ -1,0 +1,151 @@
+"""Seeded random shapes through the DEFAULT dispatch of gptq_marlin_gemm (decode kernel, row-block kernel with and without
+K splits, wide-tile kernel, large-tile kernel; padding workgroups, ragged row blocks, K that does not divide evenly over the
+slices) and through the fused / deferred forms of the same GEMM. The reference test fixes a shape grid
+(tests/kernels/test_marlin_gemm.py:126-179, covered by tests/test_marlin_gpu.py); dispatch here depends on (M, N, K) in
+many more ways than the reference's tile table, so this file samples the space instead. The second half does the same for
+cutlass_scaled_mm (fp8 / int8).
+
+Expected value: a @ w_ref in fp32 with w_ref = fp16((q - 8) * s), the reference test's own expectation
+(marlin_utils.py:72-109 builds w_ref the same way), bar compute_max_diff < 0.04 as there. Weights are made on the GPU:
+random 4-bit codes packed in the GPTQ checkpoint layout (quant_utils.py:125-146, element k at bits 4 (k % 8) of row k / 8) and
+repacked by gptq_marlin_repack, which tests/test_marlin_gpu.py pins bit-exactly against the reference's packer."""
+import random
+
+import pytest
+import torch
+
+import oracle
+from oracle import packing
+from util import compute_max_diff, seed_all
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(rng):
+    M = rng.choice([1, 2, 3, 5, 8, 9, 13, 16, 17, 24, 31, 32, 33, 47, 64, 65, 96, 100, 128, 129, 200, 256, 257, 300])
+    N = 64 * rng.choice([1, 2, 3, 5, 8, 12, 16, 31, 33, 48, 64, 96, 100, 112, 128, 130, 224, 448])
+    K = 128 * rng.choice([1, 2, 3, 4, 7, 8, 11, 16, 28, 32, 33, 56, 64, 72])
+    group = rng.choice([-1, 128])
+    return M, N, K, group
+
+
+def _make(M, N, K, group, dtype, seed):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    q = torch.randint(0, 16, (K, N), dtype=torch.int32, device=DEV, generator=g)
+    groups = 1 if group == -1 else K // group
+    s = (torch.rand(groups, N, device=DEV, generator=g) * 0.01 + 0.002).to(dtype)
+    w_ref = ((q - 8).to(dtype).view(groups, K // groups, N) * s[:, None, :]).view(K, N)  # (q - 8) exact, one rounding
+    shifts = (4 * torch.arange(8, device=DEV, dtype=torch.int32)).view(1, 8, 1)
+    packed = (q.view(K // 8, 8, N) << shifts).sum(dim=1, dtype=torch.int32)  # nibbles do not overlap: sum == or
+    a = torch.randn(M, K, dtype=dtype, device=DEV, generator=g)
+    return a, packed, s, w_ref
+
+
+CASES = []
+_rng = random.Random(20240)
+while len(CASES) < 96:
+    c = _case(_rng)
+    if c not in CASES:
+        CASES.append(c)
+
+
+@pytest.mark.parametrize("M,N,K,group", CASES)
+def test_random_shape_default_dispatch(ops, M, N, K, group):
+    dtype = torch.float16 if (M + N // 64 + K // 128) % 3 else torch.bfloat16
+    seed_all(M * 7 + N + K)
+    a, packed, s, w_ref = _make(M, N, K, group, dtype, M + N + K)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(max(N // 64 * 16, 16), dtype=torch.int32, device=DEV)
+    mq = ops.gptq_marlin_repack(packed, e, K, N, 4)
+    ms = packing.marlin_permute_scales(s, K, N, group)
+    out = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, M, N, K, True)
+    ref = (a.float() @ w_ref.float())
+    torch.cuda.synchronize()
+    assert compute_max_diff(out.float().cpu(), ref.cpu()) < 0.04
+    # the deferred form: slabs summed in the reduce kernel's order -> the same bits
+    d = ops.gptq_marlin_gemm_deferred(a, mq, ms, e, e, ws, 4, M, N, K, True)
+    assert torch.equal(d.materialize().view(torch.int16), out.view(torch.int16))
+    # gate | up halves + silu_and_mul as one op: the same bits as the two ops
+    if N % 128 == 0:
+        two = torch.empty(M, N // 2, dtype=dtype, device=DEV)
+        ops.silu_and_mul(two, out)
+        one = ops.gptq_marlin_gemm_silu_and_mul(a, mq, ms, e, e, ws, 4, M, N, K, True)
+        torch.cuda.synchronize()
+        assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K,group", CASES[:16])
+def test_random_shape_oracle_slice(ops, M, N, K, group):
+    """the same launches against the CPU oracle GEMM on a column slice (the oracle walks every weight: seconds at full size)"""
+    a, packed, s, _ = _make(M, N, K, group, torch.float16, M + N + K)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(max(N // 64 * 16, 16), dtype=torch.int32, device=DEV)
+    mq = ops.gptq_marlin_repack(packed, e, K, N, 4)
+    ms = packing.marlin_permute_scales(s, K, N, group)
+    out = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, M, N, K, True).cpu()
+    cols = min(N, 128)
+    # the first `cols` columns are whole 64-column Marlin groups: 128 words per k-tile row and group, scales permuted
+    # inside 64- (grouped) / 32-column (channel-wise) chunks
+    mq_c = mq[:, :cols * 2].contiguous().cpu()
+    ms_c = ms.cpu().reshape(-1, N // 64, 64)[:, :cols // 64].reshape(-1, cols).contiguous()
+    orc = oracle.gptq_marlin_gemm(a.cpu(), mq_c, ms_c, None, None, None, 4, M, cols, K, True)
+    assert compute_max_diff(out[:, :cols].float(), orc.float()) < 1e-2
+
+
+# ---- cutlass_scaled_mm (fp8 x fp8, int8 x int8): per-wave K-slice kernels (M <= 64), tile kernel with / without K splits ----
+def _mm_case(rng):
+    m = rng.choice([1, 3, 16, 17, 33, 64, 65, 100, 128, 130, 256, 300])
+    n = 16 * rng.choice([1, 4, 5, 16, 31, 64, 69, 96, 256, 384, 1026])
+    k = 128 * rng.choice([1, 2, 3, 8, 11, 32, 33, 64, 112])
+    return m, n, k, rng.choice([True, False]), rng.choice([True, False]), rng.choice([True, False])
+
+
+MM_CASES = []
+while len(MM_CASES) < 48:
+    c = _mm_case(_rng)
+    if c not in MM_CASES:
+        MM_CASES.append(c)
+
+
+@pytest.mark.parametrize("m,n,k,is_fp8,per_token,per_channel", MM_CASES)
+def test_random_shape_scaled_mm(ops, tune, m, n, k, is_fp8, per_token, per_channel):
+    """default dispatch against the fp32 product on the device (test_cutlass.py:35-47's baseline and bars); int8
+    accumulates exactly, so the tile kernel and the per-wave kernels must agree bit for bit where both apply; the deferred
+    form + materialize equals the plain op bit for bit (fp8, per-tensor scales)."""
+    g = torch.Generator(device=DEV)
+    g.manual_seed(m + n + k)
+    out_dtype = torch.bfloat16 if is_fp8 else torch.float16
+    if is_fp8:
+        a = torch.randn(m, k, device=DEV, generator=g).clamp(-448, 448).round().to(torch.float8_e4m3fn)
+        b = torch.randn(n, k, device=DEV, generator=g).clamp(-448, 448).round().to(torch.float8_e4m3fn)
+    else:
+        a = (torch.randn(m, k, device=DEV, generator=g) * 5).clamp(-128, 127).round().to(torch.int8)
+        b = (torch.randn(n, k, device=DEV, generator=g) * 5).clamp(-128, 127).round().to(torch.int8)
+    sa = torch.rand((m, 1) if per_token else (1, 1), device=DEV, generator=g) / 10 + 0.01
+    sb = torch.rand((1, n) if per_channel else (1, 1), device=DEV, generator=g) / 10 + 0.01
+    out = ops.cutlass_scaled_mm(a, b.t(), sa, sb, out_dtype)
+    base = (sa * (sb * torch.mm(a.float(), b.float().t()))).to(out_dtype)
+    torch.testing.assert_close(out, base, rtol=1e-2, atol=5e-2 if is_fp8 else 1e-1)
+    if not is_fp8:
+        tune(NMX_MM_TILE="0")
+        other = ops.cutlass_scaled_mm(a, b.t(), sa, sb, out_dtype)
+        tune(NMX_MM_TILE=None)
+        assert torch.equal(out, other)
+    elif not per_token and not per_channel:
+        plain = ops.cutlass_scaled_mm(a, b.t(), sa, sb, torch.float16)
+        d = ops.cutlass_scaled_mm_deferred(a, b.t(), sa, sb, torch.float16)  # slabs live in the scratch: consume at once
+        if d.splits > 1:  # the consumer ops apply sa * (sb * sum) and round once, like the reduce launch's epilogue
+            res0 = torch.zeros(m, n, dtype=torch.float16, device=DEV)
+            w1 = torch.ones(n, dtype=torch.float16, device=DEV)
+            r_plain = res0.clone()
+            x_plain = plain.clone()
+            ops.fused_add_rms_norm(x_plain, r_plain, w1, 1e-5)
+            r_fused = res0.clone()
+            x_fused = ops.fused_add_rms_norm_splitk(d, r_fused, w1, 1e-5)
+            torch.cuda.synchronize()
+            assert torch.equal(r_plain.view(torch.int16), r_fused.view(torch.int16))  # residual = the GEMM output itself
+            assert torch.equal(x_plain.view(torch.int16), x_fused.view(torch.int16))
+        else:
+            assert torch.equal(d.out.view(torch.int16), plain.view(torch.int16))
