@@ -149,3 +149,86 @@ def test_random_shape_scaled_mm(ops, tune, m, n, k, is_fp8, per_token, per_chann
             assert torch.equal(x_plain.view(torch.int16), x_fused.view(torch.int16))
         else:
             assert torch.equal(d.out.view(torch.int16), plain.view(torch.int16))
+
+
+# ---- paged_attention v1 / v2: head layouts, head sizes, block sizes and sequence-length mixes the fixed grids do not combine ----
+def _attn_case(rng):
+    nkv = rng.choice([1, 2, 4, 8])
+    qpk = rng.choice([1, 2, 4, 5, 7, 8, 16, 17, 32])
+    if nkv * qpk > 64:
+        nkv = max(1, 64 // qpk)
+    head = rng.choice([64, 80, 96, 112, 128, 192, 256])
+    bs = rng.choice([8, 16, 32])
+    dtype = rng.choice([torch.half, torch.bfloat16])
+    kv = rng.choice(["auto", "auto", "fp8", "fp8_e5m2"])
+    nseq = rng.choice([1, 2, 3, 7, 12])
+    lens = [rng.choice([1, 2, 15, 16, 17, 31, 33, 100, 511, 512, 513, 777, 1024, 1025, 1536, 1537]) for _ in range(nseq)]
+    return rng.choice(["v1", "v2"]), nkv * qpk, nkv, head, bs, dtype, kv, tuple(lens), rng.choice([False, False, True])
+
+
+ATTN_CASES = []
+while len(ATTN_CASES) < 64:
+    c = _attn_case(_rng)
+    if c not in ATTN_CASES:
+        ATTN_CASES.append(c)
+
+
+@pytest.mark.parametrize("version,nq,nkv,head,bs,dtype,kv,lens,alibi", ATTN_CASES)
+def test_random_paged_attention(ops, version, nq, nkv, head, bs, dtype, kv, lens, alibi):
+    """against the CPU oracle (attention_kernels.cu:86-669 restated), the bar of tests/kernels/test_attention.py:119-284"""
+    from test_attention_gpu import run_hip, run_oracle
+    from util import create_kv_caches_with_random
+    seed_all(nq * 3 + head + len(lens))
+    rnd = random.Random(nq + head + sum(lens))
+    scale = float(head**-0.5)
+    nseq, nblocks = len(lens), 300
+    q = torch.empty(nseq, nq, head, dtype=dtype).uniform_(-scale, scale)
+    max_len = max(lens)
+    mb = (max_len + bs - 1) // bs
+    bt = torch.tensor([[rnd.randint(0, nblocks - 1) for _ in range(mb)] for _ in range(nseq)], dtype=torch.int32)
+    sl = torch.tensor(lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(nblocks, bs, 1, nkv, head, kv, dtype)
+    slopes = torch.randn(nq, dtype=torch.float32) if alibi else None
+    kv_scale = 0.6 if kv != "auto" else 1.0
+    out = run_hip(ops, version, q, kcs[0], vcs[0], nkv, scale, bt, sl, bs, max_len, slopes, kv, kv_scale)
+    orc = run_oracle(version, q, kcs[0], vcs[0], nkv, scale, bt, sl, bs, max_len, slopes, kv, kv_scale)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float(), orc.float(), atol=1e-2 if kv != "auto" else 2e-3, rtol=1e-5)
+
+
+# ---- AWQ on the Marlin kernel and the checkpoint-layout awq_gemm: the two device paths of one checkpoint must agree ----
+def _awq_case(rng):
+    # awq_gemm checks OC % group_size == 0 like the reference (gemm_kernels.cu:505-513): N in multiples of 128; the Marlin
+    # path needs >= 2 groups of 128
+    return (rng.choice([1, 4, 8, 16, 17, 40, 64, 65, 128, 200, 256]), 128 * rng.choice([1, 2, 3, 8, 10, 32, 56, 64]),
+            128 * rng.choice([2, 3, 5, 8, 28, 32, 64]))
+
+
+AWQ_CASES = []
+while len(AWQ_CASES) < 32:
+    c = _awq_case(_rng)
+    if c not in AWQ_CASES:
+        AWQ_CASES.append(c)
+
+
+@pytest.mark.parametrize("M,N,K", AWQ_CASES)
+def test_random_shape_awq_paths(ops, M, N, K):
+    """awq_marlin_gemm (load-time repack) == awq_gemm (checkpoint layout) to rounding, both == a @ ((q - z) * s) to the GEMM
+    bar; the deferred form of the Marlin path equals its plain form bit for bit."""
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + N + K)
+    groups = K // 128
+    qw = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int32, device=DEV, generator=g)
+    qz = torch.randint(-2**31, 2**31 - 1, (groups, N // 8), dtype=torch.int32, device=DEV, generator=g)
+    sc = (torch.rand(groups, N, device=DEV, generator=g) * 0.004 + 0.002).to(torch.float16)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV, generator=g)
+    mq, ms, mz = ops.awq_marlin_repack(qw, qz, sc)
+    marlin = ops.awq_marlin_gemm(a, mq, ms, mz, M, N, K)
+    direct = ops.awq_gemm(a, qw, sc, qz, 8)
+    w = ops.awq_dequantize(qw, sc, qz, 0, 0, 0)  # [K, N] fp16: (q - z) * s in the reference's arithmetic
+    ref = a.float() @ w.float()
+    torch.cuda.synchronize()
+    assert compute_max_diff(marlin.float().cpu(), ref.cpu()) < 0.04
+    assert compute_max_diff(direct.float().cpu(), ref.cpu()) < 0.04
+    d = ops.awq_marlin_gemm_deferred(a, mq, ms, mz, M, N, K)
+    assert torch.equal(d.materialize().view(torch.int16), marlin.view(torch.int16))
