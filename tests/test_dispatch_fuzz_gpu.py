@@ -232,3 +232,42 @@ def test_random_shape_awq_paths(ops, M, N, K):
     assert compute_max_diff(direct.float().cpu(), ref.cpu()) < 0.04
     d = ops.awq_marlin_gemm_deferred(a, mq, ms, mz, M, N, K)
     assert torch.equal(d.materialize().view(torch.int16), marlin.view(torch.int16))
+
+
+# ---- context_attention_fwd (prefill over paged context + new tokens): shared-LDS and per-wave kernels, every masking rule ----
+def _prefill_case(rng):
+    hkv = rng.choice([1, 2, 3, 4, 8])
+    qpk = rng.choice([1, 2, 3, 4, 8])
+    head = rng.choice([64, 80, 96, 112, 128, 192, 256])
+    bs = rng.choice([8, 16, 32])
+    dtype = rng.choice([torch.float16, torch.bfloat16])
+    batch = rng.choice([1, 2, 5, 9])
+    max_q = rng.choice([1, 7, 16, 63, 64, 65, 130, 300])
+    max_ctx = rng.choice([0, 5, 16, 100, 257, 600])
+    window = rng.choice([0, 0, 0, 8, 100])
+    alibi = rng.choice([False, False, True])
+    return hkv * qpk, hkv, head, bs, dtype, batch, max_q, max_ctx, window, alibi, rng.randint(0, 10**6)
+
+
+PREFILL_CASES = []
+while len(PREFILL_CASES) < 48:
+    c = _prefill_case(_rng)
+    if c not in PREFILL_CASES:
+        PREFILL_CASES.append(c)
+
+
+@pytest.mark.parametrize("H,Hkv,D,bs,dtype,batch,max_q,max_ctx,window,alibi,seed", PREFILL_CASES)
+def test_random_prefill_attention(ops, H, Hkv, D, bs, dtype, batch, max_q, max_ctx, window, alibi, seed):
+    """against the CPU oracle (prefix_prefill.py:674-812 restated; parity unpinned) with the bars of
+    tests/test_prefill_gpu.py"""
+    import test_prefill_gpu as P
+    seed_all(seed)
+    c = P.make_case(batch, H, Hkv, D, bs, dtype, max_q=max_q, max_ctx=max_ctx, cache_blocks=max(256, batch * ((max_ctx + bs - 1) // bs + 2)))
+    slopes = (torch.rand(H) * 0.3) if alibi else None
+    if alibi and window:
+        window = 0  # the reference's alibi path has no sliding window (prefix_prefill.py:765-797)
+    out = P.run_hip(c, alibi=slopes, window=window)
+    orc = P.run_oracle(c, alibi=slopes, window=window)
+    assert not torch.isnan(out).any()
+    tol = dict(atol=2e-3, rtol=2e-3) if dtype == torch.float16 else dict(atol=1.5e-2, rtol=1.5e-2)
+    torch.testing.assert_close(out.float(), orc.float(), **tol)
