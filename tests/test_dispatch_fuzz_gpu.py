@@ -271,3 +271,122 @@ def test_random_prefill_attention(ops, H, Hkv, D, bs, dtype, batch, max_q, max_c
     assert not torch.isnan(out).any()
     tol = dict(atol=2e-3, rtol=2e-3) if dtype == torch.float16 else dict(atol=1.5e-2, rtol=1.5e-2)
     torch.testing.assert_close(out.float(), orc.float(), **tol)
+
+
+# ---- 8-bit GPTQ-Marlin and fp8-Marlin (W8A16) through the default dispatch ----
+W8_CASES = []
+while len(W8_CASES) < 40:
+    c = _case(_rng)[:3] + (_rng.choice([-1, 128]), _rng.choice(["int8", "fp8"]))
+    if c not in W8_CASES:
+        W8_CASES.append(c)
+
+
+@pytest.mark.parametrize("M,N,K,group,kind", W8_CASES)
+def test_random_shape_w8a16(ops, M, N, K, group, kind):
+    """gptq_marlin_gemm with 8-bit weights / fp8_marlin_gemm (channel-wise scales: fp8.py:258-287) against a @ w_ref, the
+    reference test's expectation and bar (tests/kernels/test_marlin_gemm.py:126-179, 238-304)"""
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + N + K)
+    dtype = torch.float16 if (M + K // 128) % 2 else torch.bfloat16
+    a = torch.randn(M, K, dtype=dtype, device=DEV, generator=g)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(max(N // 64 * 16, 16), dtype=torch.int32, device=DEV)
+    shifts = (8 * torch.arange(4, device=DEV, dtype=torch.int32)).view(1, 4, 1)
+    if kind == "int8":
+        q = torch.randint(0, 256, (K, N), dtype=torch.int32, device=DEV, generator=g)
+        groups = 1 if group == -1 else K // group
+        s = (torch.rand(groups, N, device=DEV, generator=g) * 0.001 + 0.0002).to(dtype)
+        w_ref = ((q - 128).to(dtype).view(groups, K // groups, N) * s[:, None, :]).view(K, N)
+        packed = (q.view(K // 4, 4, N) << shifts).sum(dim=1, dtype=torch.int32)
+        mq = ops.gptq_marlin_repack(packed, e, K, N, 8)
+        ms = packing.marlin_permute_scales(s, K, N, group)
+        out = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 8, M, N, K, True)
+        d = ops.gptq_marlin_gemm_deferred(a, mq, ms, e, e, ws, 8, M, N, K, True)
+        assert torch.equal(d.materialize().view(torch.int16), out.view(torch.int16))
+    else:
+        w8 = (torch.randn(K, N, device=DEV, generator=g) * 2).to(torch.float8_e4m3fn)
+        q = w8.view(torch.uint8).to(torch.int32)
+        packed = (q.view(K // 4, 4, N) << shifts).sum(dim=1, dtype=torch.int32)  # marlin_utils.py:226-247
+        mq = ops.gptq_marlin_repack(packed, e, K, N, 8)
+        s = (torch.rand(1, N, device=DEV, generator=g) * 0.01 + 0.002).to(dtype)
+        ms = packing.marlin_permute_scales(s, K, N, -1)
+        w_ref = (w8.to(dtype) * s)
+        out = ops.fp8_marlin_gemm(a, mq, ms, ws, 8, M, N, K)
+    ref = a.float() @ w_ref.float()
+    torch.cuda.synchronize()
+    assert compute_max_diff(out.float().cpu(), ref.cpu()) < 0.04
+
+
+# ---- fused consumers of a deferred GEMM: rotary + KV-cache write, residual add + RMS norm ----
+def _rope_case(rng):
+    kvh = rng.choice([1, 2, 4, 8])
+    qpk = rng.choice([1, 2, 4, 7])
+    D = rng.choice([64, 96, 128, 256])
+    while ((kvh * qpk + 2 * kvh) * D) % 64:
+        kvh *= 2
+    return (rng.choice([1, 3, 8, 16, 33, 64, 100, 256]), kvh * qpk, kvh, D, rng.choice([8, 16, 32]), rng.choice(["auto", "fp8"]),
+            128 * rng.choice([2, 8, 32]))
+
+
+ROPE_CASES = []
+while len(ROPE_CASES) < 32:
+    c = _rope_case(_rng)
+    if c not in ROPE_CASES:
+        ROPE_CASES.append(c)
+
+
+@pytest.mark.parametrize("M,H,KVH,D,BS,kv_dtype,K", ROPE_CASES)
+def test_random_rope_reshape_and_cache(ops, M, H, KVH, D, BS, kv_dtype, K):
+    """qkv GEMM (deferred or not, as the dispatch decides) -> rotary + cache write in one launch == gptq_marlin_gemm ->
+    rotary_embedding -> reshape_and_cache, bit for bit (pos_encoding_kernels.cu:10-96, cache_kernels.cu:153-278)"""
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + H + D + K)
+    N, NB = (H + 2 * KVH) * D, 64
+    mq = torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32, device=DEV, generator=g)
+    ms = (torch.rand(K // 128, N, device=DEV, generator=g) * 0.004 + 0.002).to(torch.float16)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV, generator=g)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
+    plain = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, M, N, K, True)
+    cos_sin = torch.randn(512, D, device=DEV, generator=g).half()
+    positions = torch.randint(0, 512, (M, ), device=DEV, generator=g)
+    slots = torch.randperm(NB * BS, device=DEV, generator=g)[:M].long() if M <= NB * BS else None
+    if M > 2:
+        slots[1] = -1
+    cdt = torch.uint8 if kv_dtype == "fp8" else torch.float16
+    x = 16 if kv_dtype == "fp8" else 8
+    kc0 = torch.randint(0, 100, (NB, KVH, D // x, BS, x), device=DEV, generator=g).to(cdt)
+    vc0 = torch.randint(0, 100, (NB, KVH, D, BS), device=DEV, generator=g).to(cdt)
+    kv_scale = 0.05 if kv_dtype == "fp8" else 1.0
+    kc_a, vc_a = kc0.clone(), vc0.clone()
+    qa, ka, va = plain.split([H * D, KVH * D, KVH * D], dim=-1)
+    ops.rotary_embedding(positions, qa, ka, D, cos_sin, True)
+    ops.reshape_and_cache(ka.view(-1, KVH, D), va.view(-1, KVH, D), kc_a, vc_a, slots, kv_dtype, kv_scale)
+    kc_b, vc_b = kc0.clone(), vc0.clone()
+    d = ops.gptq_marlin_gemm_deferred(a, mq, ms, e, e, ws, 4, M, N, K, True)
+    qkv = ops.rope_reshape_and_cache(positions, d, H, KVH, D, cos_sin, kc_b, vc_b, slots, kv_dtype, kv_scale)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv.view(torch.int16), plain.view(torch.int16))
+    assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
+
+
+@pytest.mark.parametrize("M,N,K", [(m, 64 * n, 128 * k) for m, n, k in
+                                   [(1, 16, 32), (3, 33, 8), (16, 64, 32), (17, 5, 64), (64, 64, 112), (65, 128, 8), (100, 31, 33),
+                                    (256, 64, 32), (300, 16, 112), (8, 224, 16), (33, 96, 28), (128, 112, 56)]])
+def test_random_add_rms_norm_consumer(ops, M, N, K):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + N + K)
+    mq = torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32, device=DEV, generator=g)
+    ms = (torch.rand(K // 128, N, device=DEV, generator=g) * 0.004 + 0.002).to(torch.float16)
+    a = torch.randn(M, K, dtype=torch.float16, device=DEV, generator=g)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
+    plain = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, M, N, K, True)
+    res0 = torch.randn(M, N, dtype=torch.float16, device=DEV, generator=g)
+    w = (torch.rand(N, device=DEV, generator=g) + 0.5).half()
+    res_a, res_b = res0.clone(), res0.clone()
+    ops.fused_add_rms_norm(plain, res_a, w, 1e-5)
+    d = ops.gptq_marlin_gemm_deferred(a, mq, ms, e, e, ws, 4, M, N, K, True)
+    fused = ops.fused_add_rms_norm_splitk(d, res_b, w, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), plain.view(torch.int16)) and torch.equal(res_a.view(torch.int16), res_b.view(torch.int16))
