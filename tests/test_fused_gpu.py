@@ -77,20 +77,23 @@ def test_deferred_gemm_silu_and_mul(ops, M):
     torch.testing.assert_close(out_b.cpu().float(), out_o.float(), atol=2e-3, rtol=2e-3)
 
 
-def _gate_up_case(ops, M, K, N, dtype, grouped, seed):
+def _gate_up_case(ops, M, K, N, dtype, grouped, seed, bits=4):
     """(two-op result, one-op result) of silu_and_mul(gptq_marlin_gemm(a, w)) on the same operands"""
     seed_all(seed)
     q, s = _weights(K, N, seed)
+    if bits == 8:  # twice the packed words per k-tile row; scales sized for |q - 128| <= 128
+        q = torch.cat([q, q.flip(1)], dim=1).contiguous()
+        s = (s / 16).to(s.dtype)
     if not grouped:
         s = s[:1].contiguous()
     s = s.to(dtype)
     a = torch.randn(M, K, dtype=dtype, device=DEV)
     e = torch.empty(0, dtype=torch.int32, device=DEV)
     ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
-    plain = ops.gptq_marlin_gemm(a, q, s, e, e, ws, 4, M, N, K, True)
+    plain = ops.gptq_marlin_gemm(a, q, s, e, e, ws, bits, M, N, K, True)
     two = torch.empty(M, N // 2, dtype=dtype, device=DEV)
     ops.silu_and_mul(two, plain)
-    one = ops.gptq_marlin_gemm_silu_and_mul(a, q, s, e, e, ws, 4, M, N, K, True)
+    one = ops.gptq_marlin_gemm_silu_and_mul(a, q, s, e, e, ws, bits, M, N, K, True)
     torch.cuda.synchronize()
     return plain, two, one
 
@@ -108,6 +111,15 @@ def test_gate_up_gemm_silu_and_mul(ops, M, dtype):
     oracle.act_and_mul(out_o, plain.cpu(), "silu")
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
     torch.testing.assert_close(one.cpu().float(), out_o.float(), atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("wide", ["1,4,1", "2,2,1"])
+def test_gate_up_gemm_silu_and_mul_int8(ops, tune, wide):
+    """8-bit weights through the wide kernel's fused epilogue (the 64-row shapes are 4-bit only)"""
+    K, N, M = 1024, 2 * 1280, 200
+    tune(NMX_GEMM_WIDE=wide)
+    _, two, one = _gate_up_case(ops, M, K, N, torch.float16, True, 12, bits=8)
+    assert torch.isfinite(one.float()).all() and torch.equal(_bits(two), _bits(one))
 
 
 @pytest.mark.parametrize("wide", ["1,4,1", "1,2,1", "2,2,1", "2,4,1", "1,2,1,4", "1,4,1,4", "1,4,2"])
