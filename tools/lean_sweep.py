@@ -69,9 +69,9 @@ def cfgs_for(name, M):
             out += ["W:2,2,1", "W:2,2,2", "W:2,4,1", "W:2,4,2"]
         return out
     if M <= 16:
-        out += ["L:16,1", "L:8,1", "L:8,2", "L:4,2", "L:4,3", "L:4,4", "L:8,1,1,0", "L:4,4,1,0"]
+        out += ["L:16,1", "L:8,1", "L:8,2", "L:4,2", "L:4,3", "L:4,4", "L:8,4", "L:4,8", "L:8,1,1,0", "L:4,4,1,0", "S:1,1,2", "S:1,1,4", "S:1,1,8"]
         if name == "down":
-            out += ["L:8,4", "L:4,8", "L:4,7"]
+            out += ["L:4,7", "L:4,14", "L:8,7", "S:1,1,7", "S:1,1,14"]
     elif M <= 32:
         out += ["L:8,1", "L:8,2", "L:4,2", "L:4,4", "L:8,1,2,0", "L:4,2,2,0", "S:2,2,2", "S:2,2,4"]
         if name == "down":
@@ -106,9 +106,14 @@ def main():
                     torch.cuda.synchronize()
                     err = ((out - ref).abs().mean() / ref.abs().mean()).item()
 
+                    defer = os.environ.get("LEAN_SWEEP_DEFER") == "1"  # GEMM only: the split-K slabs stay for a consumer
+
                     def run():
                         for w in ws:
-                            ops.gptq_marlin_gemm(x, w[0], w[1], e, e, wsp, 4, M, N, K, True)
+                            if defer:
+                                ops.gptq_marlin_gemm_deferred(x, w[0], w[1], e, e, wsp, 4, M, N, K, True)
+                            else:
+                                ops.gptq_marlin_gemm(x, w[0], w[1], e, e, wsp, 4, M, N, K, True)
 
                     us = time_graph(run) / NL
                     print(f"{name:8} M={M:4d} {cfg:12} {us:7.2f} us  {by / us / 1e3:7.0f} GB/s  {2.0 * M * K * N / us / 1e6:7.1f} TFLOP/s  relerr_vs_default={err:.2e}", flush=True)
