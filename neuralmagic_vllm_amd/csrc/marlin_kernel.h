@@ -235,8 +235,9 @@ struct GemmParams {
   int k_splits;
   int slow_act_order;      // act-order with partial K: per-row scale lookup
   int defer_reduce;        // k_splits > 1: leave the fp32 slabs in `partial` for the consumer (no reduce launch)
-  void* act_out = nullptr; // gate_up + silu_and_mul in one launch: [M, N / 2]; the kernels that can do it (marlin_wide,
-                           // no K split) write silu(c[:, :N/2]) * c[:, N/2:] here INSTEAD of c and set act_done
+  void* act_out = nullptr; // gate_up + silu_and_mul in one launch: [M, N / 2]. A launch without a K split of marlin_wide,
+                           // of marlin_gemm_kernel's 16-row shape or of marlin_decode_kernel writes silu(c[:, :N/2]) *
+                           // c[:, N/2:] here INSTEAD of c and the host sets act_done; every other path leaves it alone
   int act_done = 0;        // host side only
   int xcd_split = 1;       // marlin_gemm_kernel: 2 / 4 / 8 K splits are placed one per group of XCDs (NMX_GEMM_XCD_SPLIT=0: off)
 };
