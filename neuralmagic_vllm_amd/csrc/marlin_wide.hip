@@ -677,8 +677,11 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
   } else if (kind == W_INT4 && M <= 256 && K <= 4096 && N <= 8192) {
     // small matrices (qkv, o) at 64 < M <= 256: 64-row x 128-column tiles, no K split when they alone give >= 192
     // workgroups, else two (tools/lean_sweep.py: qkv 27.1 vs 31.0 us at M = 256, 21.6 vs 25.2 at 128; o 22.6 vs 24.2, 19.7 vs 23.5)
+    // Two K splits while both halves still fit the chip in one round (<= 256 workgroups); above that the second round's tail
+    // costs more than idle CUs do (deferred reduce, tools/lean_sweep.py LEAN_SWEEP_DEFER=1: qkv at M = 192, 144 tiles: 23.6 us
+    // unsplit vs 30.5 split; o at M = 256, 128 tiles: 22.5 unsplit vs 17.3 split)
     c.wm = 1; c.wn = 2; c.mt = 4;
-    c.splits = ceil_div(N, 128) * ceil_div(M, 64) >= 192 ? 1 : 2;
+    c.splits = ceil_div(N, 128) * ceil_div(M, 64) * 2 <= 256 ? 2 : 1;
   } else if (M <= 128 && K <= 8192 && ceil_div(N, 128) >= 192) {
     // gate_up-like at 64 < M <= 128: one row block, 128-column tiles fill the chip without a split (41.0 vs 47.9 us)
     c.wm = 1; c.wn = 2; c.splits = 1;
@@ -693,8 +696,11 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
     const int units = ceil_div(N, 256) * ceil_div(M, 128);
     c.splits = 1;
     if (units < 192) {
-      if (K < 8192 || units < 64) return false;
-      while (units * c.splits * 2 <= 256 && stages / (c.splits * 2 * 2) >= 16) c.splits *= 2;
+      // long K, few tiles: K splits across workgroups down to 14 stages per wave (down_proj at M = 256: 32 tiles x 8 splits,
+      // 36.1 us against 42.8 on the row-block kernel, deferred reduce; M = 192: 34.1 vs 38.4; at M = 128 the 16 tiles do
+      // not fill the chip and the row-block kernel stays)
+      if (K < 8192 || units < 32) return false;
+      while (units * c.splits * 2 <= 256 && stages / (c.splits * 2 * 2) >= 14) c.splits *= 2;
       if (units * c.splits < 192) return false;
     }
   }
