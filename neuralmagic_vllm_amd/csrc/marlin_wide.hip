@@ -677,11 +677,14 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
   } else if (kind == W_INT4 && M <= 256 && K <= 4096 && N <= 8192) {
     // small matrices (qkv, o) at 64 < M <= 256: 64-row x 128-column tiles, no K split when they alone give >= 192
     // workgroups, else two (tools/lean_sweep.py: qkv 27.1 vs 31.0 us at M = 256, 21.6 vs 25.2 at 128; o 22.6 vs 24.2, 19.7 vs 23.5)
-    // Two K splits while both halves still fit the chip in one round (<= 256 workgroups); above that the second round's tail
+    // K splits (2 or 4) while all of them still fit the chip in one round (<= 256 workgroups); above that the second round's tail
     // costs more than idle CUs do (deferred reduce, tools/lean_sweep.py LEAN_SWEEP_DEFER=1: qkv at M = 192, 144 tiles: 23.6 us
     // unsplit vs 30.5 split; o at M = 256, 128 tiles: 22.5 unsplit vs 17.3 split)
+    // (o at M = 80 .. 128, 64 tiles: 4 splits 12.3-12.8 us vs 15.5-15.7 with 2)
     c.wm = 1; c.wn = 2; c.mt = 4;
-    c.splits = ceil_div(N, 128) * ceil_div(M, 64) * 2 <= 256 ? 2 : 1;
+    const int units64 = ceil_div(N, 128) * ceil_div(M, 64);
+    c.splits = 1;
+    while (c.splits < 4 && units64 * c.splits * 2 <= 256 && stages / (c.splits * 2 * 4) >= 4) c.splits *= 2;
   } else if (M <= 128 && K <= 8192 && ceil_div(N, 128) >= 192) {
     // gate_up-like at 64 < M <= 128: one row block, 128-column tiles fill the chip without a split (41.0 vs 47.9 us)
     c.wm = 1; c.wn = 2; c.splits = 1;
