@@ -724,6 +724,14 @@ def main():
         if tp > 0:
             result["tp"] = tp
             result["allreduce"] = ar_stats
+            # the communicator as torch.distributed / RCCL see it: ranks in the default group that
+            # carried the all-reduces above, the backend name and the RCCL version linked into torch
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+            result["rccl"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "version": ver,
+                              "rank0_device": str(dev)}
         if args.sweep and args.config == "int4":
             result["sweep"] = sweep(ops, cfg, dev)
         if not args.no_cpu_baseline and args.config == "int4" and world == 1:  # headline workload, single-GPU run only

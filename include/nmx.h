@@ -182,6 +182,11 @@ int nmx_silu_and_mul_splitk(void* out, const float* partial, int splits, int num
 int nmx_scaled_mm_deferred(void* out, const void* a, const void* b, const float* a_scale, const float* b_scale, void* scratch,
                            int64_t scratch_bytes, int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
                            int* splits_out, nmx_stream_t stream);
+/* out [m, n] (row stride ldc) = out_t(sa * (sb * sum_s partial[s])), s = 0, 1, ...: the reduce + scale epilogue of a K-split
+ * nmx_scaled_mm as an op of its own, for consumers of nmx_scaled_mm_deferred without a fused form (same bits as nmx_scaled_mm;
+ * reference epilogue order: tests/kernels/test_cutlass.py:35-47, csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:47-100). */
+int nmx_splitk_reduce_scaled(void* out, const float* partial, int splits, const float* a_scale, const float* b_scale, int m, int n,
+                             int64_t ldc, int out_dtype, nmx_stream_t stream);
 int nmx_fused_add_rms_norm_splitk_scaled(void* input_out, const float* partial, int splits, const float* sa, const float* sb,
                                          void* residual, const void* weight, float epsilon, int num_tokens, int hidden_size,
                                          int dtype, float* absmax, nmx_stream_t stream);
@@ -369,19 +374,32 @@ int nmx_moe_scaled_mm(void* out, const void* a, const void* w, const float* a_sc
                       const int32_t* num_tokens_post_padded, int num_valid, int a_rows, int a_row_div, int n, int k,
                       int num_experts, int block_rows, int max_blocks, int out_dtype, nmx_stream_t stream);
 
-/* ------------------------------------------------------------------------------------------------------------
- * One-shot all-reduce over the xGMI mesh for small messages. Replaces the `_C_custom_ar` ops of the reference
- * (csrc/custom_all_reduce.cu: meta_size, init_custom_ar, register_buffer, should_custom_ar, all_reduce_reg, dispose;
- * kernel csrc/custom_all_reduce.cuh:179-255, thresholds :442-450). The host side exchanges IPC handles
- * (nmx_ipc_*: hipIpcGetMemHandle / hipIpcOpenMemHandle, 64-byte handles) and hands over every rank's pointers as
- * mapped in the calling process. Only the one-stage schedule exists: nmx_custom_ar_should() is true for the sizes it
- * serves (world 2: <= max_size; full mesh: < 512 KiB at <= 4 ranks, < 256 KiB at 6 / 8), everything else stays on RCCL.
- * ---------------------------------------------------------------------------------------------------------- */
+/*
+ * All-reduce over the xGMI mesh for decode-sized messages. Replaces the `_C_custom_ar` ops of the reference
+ * (csrc/custom_all_reduce.cu: meta_size, init_custom_ar, register_buffer, should_custom_ar, all_reduce_reg, dispose; kernels
+ * csrc/custom_all_reduce.cuh:179-255, schedule choice :442-450). The host side exchanges IPC handles itself (nmx_ipc_*:
+ * hipIpcGetMemHandle / hipIpcOpenMemHandle, 64-byte handles) and hands over every rank's pointers as mapped in the calling
+ * process. Two schedules like the reference: one-stage (every rank reads every peer) for small messages, two-stage
+ * (reduce-scatter into a peer-visible scratch behind each rank's signal block, then all-gather) above the reference's
+ * thresholds; nmx_custom_ar_stages() says which, nmx_custom_ar_should() whether this communicator takes the message at all.
+ * A rank's meta block = nmx_custom_ar_meta_size() bytes of flags + its two-stage scratch (nmx_custom_ar_scratch_bytes(max
+ * message)); allocate it with nmx_custom_ar_alloc_meta (uncached fine-grained memory, zero-filled). A barrier that times out
+ * (spin bound: nmx_custom_ar_set_spin_limit) sets an error word and the call writes nothing further; read it with
+ * nmx_custom_ar_check after synchronising. nmx_custom_ar_loopback runs all ranks of one call as one launch on ONE GPU (tests).
+ */
 int64_t nmx_custom_ar_meta_size(void);
-int nmx_custom_ar_init(void* const* signal_ptrs, int rank, int world_size, void** fa_out);
+int nmx_custom_ar_alloc_meta(int64_t bytes, void** ptr);
+int nmx_custom_ar_free_meta(void* ptr);
+int nmx_custom_ar_init(void* const* signal_ptrs, int rank, int world_size, int64_t scratch_bytes, void** fa_out);
+int nmx_custom_ar_set_spin_limit(void* fa, uint32_t spin_limit);
 int nmx_custom_ar_register_buffer(void* fa, void* const* peer_ptrs);
 int nmx_custom_ar_should(int64_t bytes, int64_t max_size, int world_size, int full_xgmi);
+int nmx_custom_ar_stages(int64_t bytes, int world_size);
+int64_t nmx_custom_ar_scratch_bytes(int64_t bytes, int world_size);
 int nmx_custom_ar_all_reduce(void* fa, const void* inp, void* out, int64_t numel, int dtype, nmx_stream_t stream);
+int nmx_custom_ar_check(void* fa, int clear, int* error_out);
+int nmx_custom_ar_loopback(void* const* signal_ptrs, void* const* data_ptrs, void* const* out_ptrs, int world_size, int64_t numel,
+                           int dtype, int stages, uint32_t spin_limit, nmx_stream_t stream);
 int nmx_custom_ar_dispose(void* fa);
 int nmx_ipc_get_mem_handle(const void* ptr, void* handle64);
 int nmx_ipc_open_mem_handle(const void* handle64, void** ptr);

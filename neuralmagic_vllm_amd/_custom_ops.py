@@ -507,8 +507,11 @@ class DeferredGemm:
     def materialize(self) -> torch.Tensor:
         """Plain reduction (what the reduce launch would have produced), for consumers without a fused form."""
         if self.splits > 1:
-            if self.sa is not None:  # fp8 scaled_mm: the scale epilogue belongs to the reduction
-                self.out.copy_(self.sa * (self.sb * self.partial.sum(dim=0)))
+            if self.sa is not None:  # fp8 scaled_mm: the scale epilogue belongs to the reduction (the GEMM's own reduce kernel)
+                m, n = self.out.shape
+                _lib.check(_lib.lib().nmx_splitk_reduce_scaled(_p(self.out), _p(self.partial), c_int(self.splits), _p(self.sa),
+                                                               _p(self.sb), c_int(m), c_int(n), c_i64(self.out.stride(0)),
+                                                               c_int(_dt(self.out)), _stream(self.out)))
             else:  # the GEMMs' own reduce kernel: slabs summed in the order s = 0, 1, ... like the plain op
                 m, n = self.out.shape
                 _lib.check(_lib.lib().nmx_splitk_reduce(_p(self.out), _p(self.partial), c_int(self.splits), c_int(m), c_int(n),

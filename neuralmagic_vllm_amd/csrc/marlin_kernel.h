@@ -67,31 +67,13 @@ __device__ __forceinline__ uint32_t and_or(uint32_t q, uint32_t mask, uint32_t m
   return r;
 }
 
-// raw buffer descriptor (wave-uniform): base, num_records = bytes, untyped dword access. Loads past `bytes` return 0.
-__device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
-  const uint64_t a = (uint64_t)p;
-  i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-// Buffer loads as inline asm: destination updated in place ("+v"), per-lane byte offset in a VGPR, the wave-uniform
-// running offset in an SGPR -> no per-load VALU address arithmetic. The leading s_nop covers the SALU-write ->
-// VMEM-read hazard on the soffset / descriptor SGPRs, which hipcc does not pad inside an asm statement.
-__device__ __forceinline__ void buf_load_x2(u32x2& dst, int voff, i32x4 rsrc, int soff) {
-  soff = __builtin_amdgcn_readfirstlane(soff);  // wave-uniform by construction (depends on the wave id only)
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void buf_load_x4(u32x4& dst, int voff, i32x4 rsrc, int soff) {
-  soff = __builtin_amdgcn_readfirstlane(soff);
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-// the same with the non-temporal hint (weights that this launch reads exactly once)
-__device__ __forceinline__ void buf_load_x4_nt(u32x4& dst, int voff, i32x4 rsrc, int soff) {
-  soff = __builtin_amdgcn_readfirstlane(soff);
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+// Every vector-memory load of this file is a compiler-visible __builtin_amdgcn_raw_buffer_load_* (per-lane byte offset in a
+// VGPR, the wave-uniform running offset in an SGPR, loads past the descriptor's range return 0): hipcc counts the vmcnt
+// waits itself and never reads a destination early. (Rounds 1-2 issued the ring of marlin_gemm_kernel as inline-asm
+// loads with "+v" tied destinations and hand-counted waits; under register pressure the allocator can re-home such an
+// operand with a copy made BEFORE the load has landed. Removed in round 3.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
 __device__ __forceinline__ uint32_t h2_bits(f16x2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -633,25 +615,21 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       if (it + 1 < n_iter) body(std::integral_constant<int, 1>{}, it + 1);
     }
   } else {
-    // ---- hand-counted loop: every vector-memory op is an inline-asm load issued in a fixed periodic pattern, so
-    // that every wait is a COUNTED s_waitcnt vmcnt(N) and PF k-steps of weights stay in flight per wave.
+    // ---- fixed-pattern loop: every vector-memory op is a compiler-visible buffer load issued in one periodic order
+    // (pinned with sched_barrier), so that hipcc's own counted s_waitcnt vmcnt(N) keep PF k-steps of weights in flight.
     // Issue order per sub-chunk body:  [batch: PIECES activation loads (+ scale rows) for sub-chunk sub + AD]
-    //                                  then per k-step [wait weights(kstep)] [compute] [load weights(kstep + PF)],
-    //                                  then [wait batch(sub + 1)] [write it to LDS] [barrier].
+    //                                  then per k-step [compute(kstep)] [load weights(kstep + PF) into the freed slot],
+    //                                  then [write batch(sub + 1) to LDS] [barrier].
     // The activation tile is requested AD = 2 sub-chunks ahead (two register sets): an L2 round trip under a full
     // weight stream is ~1 us, about what a whole sub-chunk of compute takes, and with AD = 1 every iteration ended
     // on that latency (measured: a kernel with all compute removed still took 55 % of the full time).
-    // Ops younger than weights(kstep) at its wait: 2 (PF - 1) weight loads + 2 batches -> vmcnt(2 PF - 2 + 2 BATCH).
-    // Ops younger than batch(sub + 1) at the end of body `sub`: the weight loads of AD bodies + (AD - 1) batches.
-    // (vmcnt(N) with N <= #younger ops is always safe; loads past the range are clamped, never skipped, so the
-    // pattern is the same in every iteration, prologue included.)
+    // Three things keep the waits counted (the rules marlin_decode_kernel / marlin_wide_kernel were built on): the
+    // prologue queues its loads in exactly the loop's order; the loop runs whole PAIRS of bodies with nothing
+    // conditional inside (an odd sub-chunk count ends in a peeled single body - a conditional second half would put a
+    // path body 0 -> body 0 into the loop and merge its pending-load order into every wait); loads past the range are
+    // clamped / out of the descriptor's range, never skipped.
     constexpr int AD = 2;
     constexpr int NSC = (MODE == 1) ? (ACC_SCALE ? 4 : 1) : 0;  // scale loads per batch
-    constexpr int BATCH = PIECES + NSC + (ZP ? 1 : 0);
-    constexpr int WI = X4 ? 1 : 2;                    // weight load instructions per k-step
-    constexpr int WAIT_B = WI * (PF - 1) + 2 * BATCH;
-    constexpr int WAIT_BATCH = AD * WI * SUB + (AD - 1) * BATCH;
-    static_assert(WAIT_B < 60 && WAIT_BATCH < 60, "vmcnt is 6 bits");
     BStep ring[PF];
     ARegs areg[AD];
     u32x2 sraw[AD][4];
@@ -674,34 +652,36 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
     // fast modes require K % (32 SUB) == 0, so every k-tile row of an in-range k-step exists; rows past the end of
     // the matrix (prefetch beyond the slice) are out of the descriptor's range and read as zeros
     const int row_bytes = (int)(row_words * 4);
-    const i32x4 rs_b = make_rsrc(p.b, (uint32_t)((int64_t)ktiles * row_bytes));
-    const i32x4 rs_a = make_rsrc(p.a, (uint32_t)((int64_t)M * K * sizeof(scalar_t)));
-    const i32x4 rs_s = make_rsrc(p.scales, (uint32_t)((int64_t)p.num_groups * N * sizeof(scalar_t)));
-    const i32x4 rs_m = make_rsrc(SP ? p.meta : p.b, SP ? (uint32_t)((int64_t)ktiles * N * 4) : 0u);
-    const i32x4 rs_z = make_rsrc(ZP ? p.zeros : p.scales, ZP ? (uint32_t)((int64_t)p.num_groups * N * sizeof(scalar_t)) : 0u);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, (int64_t)ktiles * row_bytes);
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, (int64_t)M * K * sizeof(scalar_t));
+    const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(p.scales, (int64_t)p.num_groups * N * sizeof(scalar_t));
+    const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(SP ? p.meta : p.b, SP ? (int64_t)ktiles * N * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(ZP ? p.zeros : p.scales, ZP ? (int64_t)p.num_groups * N * sizeof(scalar_t) : 0);
     const int z_voff = (int)(scale_off * sizeof(scalar_t));  // weight layout: positions 8 c8 + 4 hi + t
     const int b_voff = X4 ? (int)((bw - p.b - 2 * hi) * 4) + hi * row_bytes : (int)((bw - p.b) * 4);
     const int m_voff = (int)(meta_off * 2);
+    // 16-row tiles and the split-free 128-column 8-wave tile only run with one row block: non-temporal weight loads
+    constexpr int W_AUX = (X4 && NMX_SKINNY_NT && (MT == 1 || (NMX_SKINNY_NT > 1 && MT == 4 && NG == 2 && W8))) ? 2 : 0;
     auto issue_b = [&](int kstep, BStep& r) {
       if constexpr ((NMX_ABLATE & 128) != 0) return;
       if constexpr (SP) {
-        if constexpr (I4) buf_load_x2(r.q0, b_voff, rs_b, kstep * row_bytes);
-        else buf_load_x4(r.q0, b_voff, rs_b, kstep * row_bytes);
-        buf_load_x4(r.q1, m_voff, rs_m, kstep * N * 4);
+        const int soff = kstep * row_bytes;  // wave-uniform (the K slice depends on the wave id only)
+        if constexpr (I4) r.q0 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff, 0);
+        else r.q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff, 0);
+        r.q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_m, m_voff, kstep * N * 4, 0);
       } else {
-        const int soff = 2 * kstep * row_bytes;  // wave-uniform
-        if constexpr (X4 && NMX_SKINNY_NT && (MT == 1 || (NMX_SKINNY_NT > 1 && MT == 4 && NG == 2 && W8))) {
-          buf_load_x4_nt(r.raw, b_voff, rs_b, soff);  // 16-row tiles are only used with one row block
-        } else if constexpr (X4) {
-          buf_load_x4(r.raw, b_voff, rs_b, soff);
+        const int soff = 2 * kstep * row_bytes;
+        if constexpr (X4) {
+          r.raw = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff, W_AUX);
         } else if constexpr (I4) {
-          buf_load_x2(r.q0, b_voff, rs_b, soff);
-          buf_load_x2(r.q1, b_voff, rs_b, soff + row_bytes);
+          r.q0 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff, 0);
+          r.q1 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff + row_bytes, 0);
         } else {
-          buf_load_x4(r.q0, b_voff, rs_b, soff);
-          buf_load_x4(r.q1, b_voff, rs_b, soff + row_bytes);
+          r.q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff, 0);
+          r.q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff + row_bytes, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);  // the load keeps the program position it is given here
     };
     // per-lane byte offsets of the activation pieces inside a [ROWS x SUB*32] slab at (m0, k = 0)
     int a_voff[PIECES];
@@ -726,22 +706,23 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       const int soff = kbase * (int)sizeof(scalar_t);  // wave-uniform
       if constexpr ((NMX_ABLATE & 64) == 0) {
 #pragma unroll
-        for (int it = 0; it < PIECES; ++it) buf_load_x4(areg[SET].v[it], a_voff[it], rs_a, soff);
+        for (int it = 0; it < PIECES; ++it) areg[SET].v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[it], soff, 0);
       }
       if constexpr (MODE == 1) {
         const int grp = min(kbase / p.group_size, p.num_groups - 1);
 #pragma unroll
         for (int r = 0; r < NSC; ++r)
-          buf_load_x2(sraw[SET][r], s_voff + 8 * r * (int)sizeof(scalar_t), rs_s, grp * N * (int)sizeof(scalar_t));
-        if constexpr (ZP) buf_load_x2(zraw[SET], z_voff, rs_z, grp * N * (int)sizeof(scalar_t));
+          sraw[SET][r] = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff + 8 * r * (int)sizeof(scalar_t), grp * N * (int)sizeof(scalar_t), 0);
+        if constexpr (ZP) zraw[SET] = __builtin_amdgcn_raw_buffer_load_b64(rs_z, z_voff, grp * N * (int)sizeof(scalar_t), 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     };
     // make the landed batch usable: zero the out-of-range pieces, write the fragments, unpack the scales
     auto land_batch = [&](int sub, bool valid, char* buf, auto set_c) {
       constexpr int SET = decltype(set_c)::value;
-      const int kbase = sub * (SUB * 32);
       // rows >= M and k >= K were read as zeros through the buffer descriptor (fast modes: K % (32 SUB) == 0 and
       // pieces beyond the tile are never stored); only a K slice that has run out of sub-chunks must be blanked
+      // (a wave-uniform branch with no load inside: the pending-load order is the same on both paths)
       if (!valid) {
 #pragma unroll
         for (int it = 0; it < PIECES; ++it) areg[SET].v[it] = u32x4{0, 0, 0, 0};
@@ -764,7 +745,13 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
           union { u32x2 v; scalar_t e[4]; } raw;
           raw.v = sraw[SET][r];
 #pragma unroll
-          for (int t = 0; t < NTILE; ++t) srow[t][r] = Scalar<scalar_t>::to_f32(raw.e[t]);
+          for (int t = 0; t < NTILE; ++t) {
+            srow[t][r] = Scalar<scalar_t>::to_f32(raw.e[t]);
+            // convert HERE: left to itself hipcc sinks the conversions to the end of the next body, keeps the raw rows
+            // alive across the re-issue of their register set and copies the new rows into place at the loop end - behind
+            // a vmcnt wait for loads that are only a few k-steps old
+            asm volatile("" : "+v"(srow[t][r]));
+          }
         }
       } else if constexpr (MODE == 1) {
         union { u32x2 v; scalar_t e[4]; } raw;
@@ -783,37 +770,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
         }
       }
     };
-    auto wait_batch = [&](auto set_c) {
-      constexpr int SET = decltype(set_c)::value;
-      ARegs& ar = areg[SET];
-      u32x2(&sr)[4] = sraw[SET];
-      u32x2& zr = zraw[SET];
-      // binds every batch destination so that no use can be scheduled above the wait
-      if constexpr (PIECES == 1)
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ar.v[0]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr)
-                     : "n"(WAIT_BATCH) : "memory");
-      else if constexpr (PIECES == 2)
-        asm volatile("s_waitcnt vmcnt(%7)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr)
-                     : "n"(WAIT_BATCH) : "memory");
-      else if constexpr (PIECES == 4)
-        asm volatile("s_waitcnt vmcnt(%9)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(sr[0]),
-                     "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr) : "n"(WAIT_BATCH) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%13)" : "+v"(ar.v[0]), "+v"(ar.v[1]), "+v"(ar.v[2]), "+v"(ar.v[3]), "+v"(ar.v[4]),
-                     "+v"(ar.v[5]), "+v"(ar.v[6]), "+v"(ar.v[7]), "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(zr)
-                     : "n"(WAIT_BATCH) : "memory");
-    };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     static_assert(PIECES == 1 || PIECES == 2 || PIECES == 4 || PIECES == 8, "unsupported activation piece count");
-    auto wait_b = [&](BStep& r) {
-      if constexpr (X4) {
-        if constexpr ((NMX_ABLATE & 16) == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r.raw) : "n"(WAIT_B) : "memory");
-        if constexpr (std::is_same<bvec_t, u32x2>::value && std::is_same<mvec_t, u32x2>::value) split_pair(r.raw, hi != 0, r.q0, r.q1);
-        return;
-      }
-      if constexpr ((NMX_ABLATE & 16) != 0) return;
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.q0), "+v"(r.q1) : "n"(WAIT_B) : "memory");
+    // X4: the lane's 16 bytes are chunk 4 c8 + g of ONE k-tile; trade the unused half with lane ^ 8
+    auto ready_b = [&](BStep& r) {
+      if constexpr (X4 && std::is_same<bvec_t, u32x2>::value && std::is_same<mvec_t, u32x2>::value) split_pair(r.raw, hi != 0, r.q0, r.q1);
     };
 
     if (n_iter > 0) {
@@ -824,7 +786,6 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
       issue_batch(sub_begin + 1, S1{});
 #pragma unroll
       for (int i = SUB; i < PF; ++i) issue_b(sub_begin * SUB + i, ring[i]);
-      wait_batch(S0{});
       land_batch(sub_begin, sub_begin < sub_end, lds_a, S0{});
     }
     sync_slice();
@@ -837,11 +798,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
 #pragma unroll
       for (int ksl = 0; ksl < SUB; ++ksl) {
         const int kstep = sub * SUB + ksl;
-        wait_b(ring[PAR * SUB + ksl]);
-        if constexpr (!ACC_SCALE) compute_step(ring[PAR * SUB + ksl], ksl, kstep, lds_a + PAR * ABUF, GA0{});
-        else if (ksl == 0) compute_step(ring[PAR * SUB + ksl], ksl, kstep, lds_a + PAR * ABUF, GA1{});
-        else compute_step(ring[PAR * SUB + ksl], ksl, kstep, lds_a + PAR * ABUF, GA2{});
-        issue_b(kstep + PF, ring[PAR * SUB + ksl]);
+        BStep& r = ring[PAR * SUB + ksl];
+        ready_b(r);
+        if constexpr (!ACC_SCALE) compute_step(r, ksl, kstep, lds_a + PAR * ABUF, GA0{});
+        else if (ksl == 0) compute_step(r, ksl, kstep, lds_a + PAR * ABUF, GA1{});
+        else compute_step(r, ksl, kstep, lds_a + PAR * ABUF, GA2{});
+        issue_b(kstep + PF, r);
       }
       if constexpr (ACC_SCALE) {
         // one group (sub-chunk) done: acc += scale[column] * group accumulator
@@ -852,28 +814,17 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][t][r] += srow[t][r] * gacc[mt][t][r];
       }
-      wait_batch(std::integral_constant<int, PAR ^ 1>{});
       land_batch(sub + 1, have_next, lds_a + (PAR ^ 1) * ABUF, std::integral_constant<int, PAR ^ 1>{});
       sync_slice();
     };
-    for (int it = 0; it < n_iter; it += 2) {
+    int it = 0;
+    for (; it + 1 < n_iter; it += 2) {
       body(std::integral_constant<int, 0>{}, it);
-      if (it + 1 < n_iter) body(std::integral_constant<int, 1>{}, it + 1);
+      body(std::integral_constant<int, 1>{}, it + 1);
     }
-    // drain: no asm load may still be in flight when its destination registers are reused below. EVERY register an
-    // asm load can still be writing must be an operand of an asm statement placed after the vmcnt(0): the compiler
-    // treats a load's destination as written at the asm statement itself, so the activation / scale registers of the
-    // last (never consumed) prefetch batches are dead to it after the loop - it put epilogue address arithmetic into
-    // them above the drain, and the landing loads then corrupted the K-slice reduction addresses.
-    if (n_iter > 0) {
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[i].q0), "+v"(ring[i].q1), "+v"(ring[i].raw)::"memory");
-      }
-      wait_batch(S0{});
-      wait_batch(S1{});
-    }
+    if (it < n_iter) body(std::integral_constant<int, 0>{}, it);  // odd count: peeled last body
   }
+
 
   // ---- channel-wise scales are applied to the fp32 accumulators (rows of D = column slots 4 g + r) ----
   if (!grouped && !slow_act) {

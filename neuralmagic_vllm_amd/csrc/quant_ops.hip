@@ -943,6 +943,29 @@ extern "C" int nmx_scaled_mm_deferred(void* out, const void* a, const void* b, c
                           true, splits_out, (hipStream_t)stream);
 }
 
+// out [m, n] = epilogue(sum_s partial[s]) for the fp32 slabs a deferred fp8 nmx_scaled_mm_deferred left behind, per-tensor
+// scales: scaled_mm_reduce_kernel itself (slabs summed s = 0, 1, ..., then sa * (sb * sum) with the fp32 product a rounding
+// step of its own), i.e. the bits the plain op would have produced. For consumers without a fused form
+// (DeferredGemm.materialize).
+extern "C" int nmx_splitk_reduce_scaled(void* out, const float* partial, int splits, const float* a_scale, const float* b_scale,
+                                        int m, int n, int64_t ldc, int out_dtype, nmx_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NMX_CHECK(out_dtype == NMX_F16 || out_dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "splitk_reduce_scaled: fp16 / bf16 output only");
+  NMX_CHECK(splits >= 1 && n % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)out % 8 == 0) && ((uintptr_t)partial % 16 == 0), NMX_ERR_INVALID_ARG,
+            "splitk_reduce_scaled: n %% 4 == 0, ldc %% 4 == 0, out 8-byte and partial 16-byte aligned");
+  NMX_CHECK(a_scale != nullptr && b_scale != nullptr, NMX_ERR_INVALID_ARG, "splitk_reduce_scaled: scales must be non-null");
+  if ((int64_t)m * n == 0) return NMX_OK;
+  MmParams p{};
+  p.out = out; p.a_scales = a_scale; p.b_scales = b_scale; p.bias = nullptr;
+  p.M = m; p.N = n; p.K = 0; p.ldc = ldc; p.a_per_row = 0; p.b_per_col = 0; p.k_splits = splits;
+  p.partial = const_cast<float*>(partial);
+  const int64_t mn4 = (int64_t)m * n / 4;
+  if (out_dtype == NMX_F16) scaled_mm_reduce_kernel<f16, true><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(p);
+  else scaled_mm_reduce_kernel<bf16, true><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(p);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
+}
+
 extern "C" int nmx_scaled_mm_supports_fp8(int capability) {
   (void)capability;
   return 1;  // gfx950 has native OCP fp8 MFMA (cutlass_scaled_mm_supports_fp8, scaled_mm_entry.cu:25-45)

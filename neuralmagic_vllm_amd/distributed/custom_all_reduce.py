@@ -1,13 +1,18 @@
-"""One-shot all-reduce over the xGMI mesh — host side. Mirrors vllm/distributed/device_communicators/custom_all_reduce.py
+"""All-reduce over the xGMI mesh - host side. Mirrors vllm/distributed/device_communicators/custom_all_reduce.py
 (CustomAllreduce: gates :37-131, IPC meta exchange :171-216, dispatch :218-262) on top of the nmx_custom_ar_* C-ABI.
 
 Differences from the reference, all deliberate:
-  * one schedule only (every rank reads every peer over its own xGMI link and sums in rank order); messages beyond the
-    one-stage thresholds return None and the caller falls back to RCCL;
+  * both schedules of the reference exist (one-stage below 512 KiB at <= 4 ranks / 256 KiB at 6-8 ranks, two-stage above,
+    csrc/custom_all_reduce.cuh:442-450), each rank reading every peer over its own xGMI link; messages beyond `max_size`
+    return None and the caller falls back to RCCL;
   * the registered staging buffer is used in every mode (eager and graph capture): the copy into it is a capturable
-    device-to-device copy of <= 256 KiB, so no graph-buffer registration pass is needed;
-  * OFF unless NMX_CUSTOM_AR=1: no multi-GPU node has measured it yet (the one-GPU loop-back test only proves the kernel
-    and the epoch barrier).
+    device-to-device copy, so no graph-buffer registration pass is needed;
+  * the signal + scratch block is uncached fine-grained device memory from nmx_custom_ar_alloc_meta (flags polled while
+    peers write them over xGMI), not a cached torch allocation;
+  * a barrier that times out sets an error word and that call writes no sum: `check()` reads it (after a sync; call it after
+    a graph replay), NMX_CUSTOM_AR_CHECK=1 makes every eager call sync and raise;
+  * OFF unless NMX_CUSTOM_AR=1: no multi-GPU node has measured it yet (the one-GPU loop-back test proves the kernels, the
+    epoch barriers and the cross-XCD visibility of flags and scratch, not the IPC mappings).
 """
 import ctypes
 import os
@@ -24,6 +29,18 @@ _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 def should_custom_ar(nbytes: int, max_size: int, world_size: int, full_xgmi: bool) -> bool:
     return bool(_lib.lib().nmx_custom_ar_should(ctypes.c_int64(nbytes), ctypes.c_int64(max_size), ctypes.c_int(world_size),
                                                 ctypes.c_int(int(full_xgmi))))
+
+
+def custom_ar_stages(nbytes: int, world_size: int) -> int:
+    """1 = one-stage (every rank reads every peer), 2 = two-stage (reduce-scatter + all-gather): csrc/custom_all_reduce.cuh:442-450."""
+    return int(_lib.lib().nmx_custom_ar_stages(ctypes.c_int64(nbytes), ctypes.c_int(world_size)))
+
+
+def custom_ar_scratch_bytes(nbytes: int, world_size: int) -> int:
+    """Peer-visible scratch a rank needs behind its signal block for a two-stage call on `nbytes` (its slice + the remainder)."""
+    lib = _lib.lib()
+    lib.nmx_custom_ar_scratch_bytes.restype = ctypes.c_int64
+    return int(lib.nmx_custom_ar_scratch_bytes(ctypes.c_int64(nbytes), ctypes.c_int(world_size)))
 
 
 def gather_ipc_meta(group, rank: int, world_size: int, shard: Tuple[bytes, int]) -> Tuple[List[bytes], List[int]]:
@@ -57,14 +74,23 @@ class CustomAllreduce:
         self.full_xgmi = True
         lib = _lib.lib()
         lib.nmx_custom_ar_meta_size.restype = ctypes.c_int64
-        self.meta = torch.zeros(int(lib.nmx_custom_ar_meta_size()), dtype=torch.uint8, device=self.device)
+        lib.nmx_custom_ar_scratch_bytes.restype = ctypes.c_int64
+        self.scratch_bytes = int(lib.nmx_custom_ar_scratch_bytes(ctypes.c_int64(max_size), ctypes.c_int(world_size)))
+        meta_bytes = int(lib.nmx_custom_ar_meta_size()) + self.scratch_bytes
+        meta = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.nmx_custom_ar_alloc_meta(ctypes.c_int64(meta_bytes), ctypes.byref(meta)))
+        self._meta = meta
         self.buffer = torch.empty(max_size, dtype=torch.uint8, device=self.device)
-        sig_ptrs = self._exchange(self.meta)
+        handle = ctypes.create_string_buffer(64)
+        _lib.check(lib.nmx_ipc_get_mem_handle(meta, handle))
+        sig_ptrs = self._exchange_raw(meta.value, (bytes(handle.raw), 0))
         fa = ctypes.c_void_p()
         _lib.check(lib.nmx_custom_ar_init((ctypes.c_void_p * world_size)(*sig_ptrs), ctypes.c_int(rank), ctypes.c_int(world_size),
-                                          ctypes.byref(fa)))
+                                          ctypes.c_int64(self.scratch_bytes), ctypes.byref(fa)))
         self._ptr = fa
         self.register_buffer(self.buffer)
+        self.check_every_call = os.environ.get("NMX_CUSTOM_AR_CHECK", "0") == "1"
         self.disabled = False
 
     # -- IPC -----------------------------------------------------------------------------------------------------
@@ -76,11 +102,14 @@ class CustomAllreduce:
 
     def _exchange(self, t: torch.Tensor) -> List[int]:
         """Pointers to every rank's copy of `t` as mapped in this process (own pointer for the own rank)."""
-        handles, offsets = gather_ipc_meta(self.group, self.rank, self.world_size, self._ipc_meta(t))
+        return self._exchange_raw(t.data_ptr(), self._ipc_meta(t))
+
+    def _exchange_raw(self, own_ptr: int, shard: Tuple[bytes, int]) -> List[int]:
+        handles, offsets = gather_ipc_meta(self.group, self.rank, self.world_size, shard)
         ptrs = []
         for r in range(self.world_size):
             if r == self.rank:
-                ptrs.append(t.data_ptr())
+                ptrs.append(own_ptr)
                 continue
             base = ctypes.c_void_p()
             _lib.check(_lib.lib().nmx_ipc_open_mem_handle(ctypes.c_char_p(handles[r]), ctypes.byref(base)))
@@ -109,7 +138,21 @@ class CustomAllreduce:
         stream = ctypes.c_void_p(torch.cuda.current_stream(input.device).cuda_stream)
         _lib.check(_lib.lib().nmx_custom_ar_all_reduce(self._ptr, ctypes.c_void_p(self.buffer.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                                        ctypes.c_int64(input.numel()), ctypes.c_int(_DT[input.dtype]), stream))
+        if self.check_every_call and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(input.device).synchronize()
+            self.check()
         return out
+
+    def check(self) -> None:
+        """Raises if a barrier of any call since the last check timed out (a late or missing peer: that call wrote no sum).
+        Reads the error word of this rank's signal block: call it after the stream / a graph replay has been synchronised."""
+        if self._ptr is None:
+            return
+        err = ctypes.c_int(0)
+        _lib.check(_lib.lib().nmx_custom_ar_check(self._ptr, ctypes.c_int(1), ctypes.byref(err)))
+        if err.value != 0:
+            raise RuntimeError("nmx custom all-reduce: a mesh barrier timed out (peer missing or not launched); the affected "
+                               "call's output is not a sum")
 
     def close(self) -> None:
         if self._ptr:
@@ -118,6 +161,9 @@ class CustomAllreduce:
         for base in self._opened:
             _lib.lib().nmx_ipc_close_mem_handle(base)
         self._opened = []
+        if getattr(self, "_meta", None):
+            _lib.lib().nmx_custom_ar_free_meta(self._meta)
+            self._meta = None
 
     def __del__(self):
         try:

@@ -13,18 +13,26 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_one_stage_thresholds():
-    from neuralmagic_vllm_amd.distributed.custom_all_reduce import should_custom_ar
+def test_schedule_thresholds():
+    from neuralmagic_vllm_amd.distributed.custom_all_reduce import custom_ar_scratch_bytes, custom_ar_stages, should_custom_ar
     mx = 8192 * 1024
     assert should_custom_ar(4 << 20, mx, 2, True) and should_custom_ar(4 << 20, mx, 2, False)   # two ranks: any size up to max
     assert not should_custom_ar(mx + 16, mx, 2, True)
-    assert should_custom_ar(512 * 1024 - 16, mx, 4, True) and not should_custom_ar(512 * 1024, mx, 4, True)
-    for w in (6, 8):
-        assert should_custom_ar(256 * 1024 - 16, mx, w, True) and not should_custom_ar(256 * 1024, mx, w, True)
+    for w in (4, 6, 8):
+        assert should_custom_ar(mx, mx, w, True) and not should_custom_ar(mx + 16, mx, w, True)
     assert not should_custom_ar(1024, mx, 4, False)       # more than two ranks need the full mesh
     assert not should_custom_ar(1000, mx, 2, True)        # 16-byte multiples only
-    # the decode message of BASELINE configs[4] at batch 8: [8, 8192] fp16 = 128 KiB -> one-shot; batch 256 -> RCCL
-    assert should_custom_ar(8 * 8192 * 2, mx, 8, True) and not should_custom_ar(256 * 8192 * 2, mx, 8, True)
+    # schedule choice of custom_all_reduce.cuh:442-450: two ranks always one-stage; <= 4 ranks below 512 KiB, <= 8 below 256 KiB
+    assert custom_ar_stages(4 << 20, 2) == 1
+    assert custom_ar_stages(512 * 1024 - 16, 4) == 1 and custom_ar_stages(512 * 1024, 4) == 2
+    for w in (6, 8):
+        assert custom_ar_stages(256 * 1024 - 16, w) == 1 and custom_ar_stages(256 * 1024, w) == 2
+    # the decode message of BASELINE configs[4]: batch 8 = [8, 8192] fp16 = 128 KiB -> one-stage; batch 256 = 4 MiB -> two-stage
+    assert custom_ar_stages(8 * 8192 * 2, 8) == 1 and custom_ar_stages(256 * 8192 * 2, 8) == 2
+    # two-stage scratch per rank: its slice of the 16-byte packets, the last rank also takes the remainder
+    assert custom_ar_scratch_bytes(256 * 8192 * 2, 8) == 256 * 8192 * 2 // 8
+    assert custom_ar_scratch_bytes(16 * 21, 4) == (21 // 4 + 21 % 4) * 16
+    assert custom_ar_scratch_bytes(mx, 6) >= mx // 6
 
 
 def test_disabled_without_gate(monkeypatch):

@@ -6,7 +6,7 @@ many more ways than the reference's tile table, so this file samples the space i
 cutlass_scaled_mm (fp8 / int8).
 
 Expected value: a @ w_ref in fp32 with w_ref = fp16((q - 8) * s), the reference test's own expectation
-(marlin_utils.py:72-109 builds w_ref the same way), bar compute_max_diff < 0.04 as there. Weights are made on the GPU:
+(marlin_utils.py:72-109 builds w_ref the same way), bar compute_max_diff < 1e-3 (fp16) / 4e-3 (bf16), tighter than the 0.04 there. Weights are made on the GPU:
 random 4-bit codes packed in the GPTQ checkpoint layout (quant_utils.py:125-146, element k at bits 4 (k % 8) of row k / 8) and
 repacked by gptq_marlin_repack, which tests/test_marlin_gpu.py pins bit-exactly against the reference's packer."""
 import random
@@ -28,6 +28,12 @@ def _case(rng):
     K = 128 * rng.choice([1, 2, 3, 4, 7, 8, 11, 16, 28, 32, 33, 56, 64, 72])
     group = rng.choice([-1, 128])
     return M, N, K, group
+
+
+def _bar(dtype):
+    """The north star's bar for the dequant GEMMs, mean|d| / mean|ref| <= 1e-3 (fp16; bf16 outputs carry 2^-9 of output
+    rounding: 4e-3) - the same bar as every grid test, NOT the reference's 0.04 (tests/kernels/test_marlin_gemm.py:114)."""
+    return 1e-3 if dtype == torch.float16 else 4e-3
 
 
 def _make(M, N, K, group, dtype, seed):
@@ -63,7 +69,7 @@ def test_random_shape_default_dispatch(ops, M, N, K, group):
     out = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, M, N, K, True)
     ref = (a.float() @ w_ref.float())
     torch.cuda.synchronize()
-    assert compute_max_diff(out.float().cpu(), ref.cpu()) < 0.04
+    assert compute_max_diff(out.float().cpu(), ref.cpu()) < _bar(dtype)
     # the deferred form: slabs summed in the reduce kernel's order -> the same bits
     d = ops.gptq_marlin_gemm_deferred(a, mq, ms, e, e, ws, 4, M, N, K, True)
     assert torch.equal(d.materialize().view(torch.int16), out.view(torch.int16))
@@ -91,7 +97,7 @@ def test_random_shape_oracle_slice(ops, M, N, K, group):
     mq_c = mq[:, :cols * 2].contiguous().cpu()
     ms_c = ms.cpu().reshape(-1, N // 64, 64)[:, :cols // 64].reshape(-1, cols).contiguous()
     orc = oracle.gptq_marlin_gemm(a.cpu(), mq_c, ms_c, None, None, None, 4, M, cols, K, True)
-    assert compute_max_diff(out[:, :cols].float(), orc.float()) < 1e-2
+    assert compute_max_diff(out[:, :cols].float(), orc.float()) < _bar(torch.float16)
 
 
 # ---- cutlass_scaled_mm (fp8 x fp8, int8 x int8): per-wave K-slice kernels (M <= 64), tile kernel with / without K splits ----
@@ -228,8 +234,8 @@ def test_random_shape_awq_paths(ops, M, N, K):
     w = ops.awq_dequantize(qw, sc, qz, 0, 0, 0)  # [K, N] fp16: (q - z) * s in the reference's arithmetic
     ref = a.float() @ w.float()
     torch.cuda.synchronize()
-    assert compute_max_diff(marlin.float().cpu(), ref.cpu()) < 0.04
-    assert compute_max_diff(direct.float().cpu(), ref.cpu()) < 0.04
+    assert compute_max_diff(marlin.float().cpu(), ref.cpu()) < _bar(torch.float16)
+    assert compute_max_diff(direct.float().cpu(), ref.cpu()) < _bar(torch.float16)
     d = ops.awq_marlin_gemm_deferred(a, mq, ms, mz, M, N, K)
     assert torch.equal(d.materialize().view(torch.int16), marlin.view(torch.int16))
 
@@ -314,7 +320,7 @@ def test_random_shape_w8a16(ops, M, N, K, group, kind):
         out = ops.fp8_marlin_gemm(a, mq, ms, ws, 8, M, N, K)
     ref = a.float() @ w_ref.float()
     torch.cuda.synchronize()
-    assert compute_max_diff(out.float().cpu(), ref.cpu()) < 0.04
+    assert compute_max_diff(out.float().cpu(), ref.cpu()) < _bar(dtype)
 
 
 # ---- fused consumers of a deferred GEMM: rotary + KV-cache write, residual add + RMS norm ----

@@ -69,6 +69,39 @@ def test_marlin_24_tile_configs(ops, size_m, num_bits):
         assert compute_max_diff(c.cpu(), a.float() @ w_24_ref.float()) < TOL, (size_k, size_n, gs)
 
 
+def random_valid_meta(rows, cols, gen):
+    """Random VALID 2:4 metadata: every nibble is (idx0 | idx1 << 2) with idx0 < idx1 (six encodings), four nibbles per int16."""
+    nibs = torch.tensor([4, 8, 12, 9, 13, 14], dtype=torch.int32)
+    m4 = nibs[torch.randint(0, 6, (rows, cols, 4), generator=gen)]
+    m = m4[..., 0] | (m4[..., 1] << 4) | (m4[..., 2] << 8) | (m4[..., 3] << 12)
+    return torch.where(m >= 32768, m - 65536, m).to(torch.int16)
+
+
+@pytest.mark.parametrize("M", [64, 256])
+@pytest.mark.parametrize("K,N", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+def test_llama3_8b_shapes_sparse24(ops, K, N, M):
+    """configs[2] (Llama-3-8B 2:4-sparse + int4) at ITS OWN workload: the four (K, N) that `bench.py --config sparse24` times,
+    default dispatch, against the oracle on a 128-column slice from both ends of N (the CUTLASS metadata reorder and the
+    scale permutation are local to 64-column groups, so a column slice of the packed tensors is itself a valid problem).
+    Random compressed words + random valid metadata: every kept-position pattern occurs."""
+    gen = torch.Generator().manual_seed(K + N + M)
+    mq = torch.randint(-2**31, 2**31 - 1, (K // 32, N * 2), dtype=torch.int32, generator=gen)
+    meta = random_valid_meta(K // 32, N * 2, gen)
+    ms = (torch.rand(K // 128, N, generator=gen) * 0.01 + 0.005).to(torch.float16)
+    a = torch.randn(M, K, dtype=torch.float16, generator=gen)
+    ws = workspace24(N)
+    c = ops.gptq_marlin_24_gemm(a.to(DEV), mq.to(DEV), meta.to(DEV), ms.to(DEV), ws, 4, M, N, K).float().cpu()
+    assert int(ws.abs().sum()) == 0
+    ncol = 128
+    for lo in (0, N - ncol):
+        orc = oracle.gptq_marlin_24_gemm(a, mq[:, lo * 2:(lo + ncol) * 2].contiguous(), meta[:, lo * 2:(lo + ncol) * 2].contiguous(),
+                                         ms[:, lo:lo + ncol].contiguous(), None, 4, M, ncol, K)
+        assert compute_max_diff(c[:, lo:lo + ncol], orc) < TOL, (K, N, M, lo)
+    # the deferred form + its consumer-side reduce must give the same bits as the plain op (what the bench's fused step runs)
+    d = ops.gptq_marlin_24_gemm_deferred(a.to(DEV), mq.to(DEV), meta.to(DEV), ms.to(DEV), ws, 4, M, N, K)
+    assert torch.equal(d.materialize().float().cpu(), c)
+
+
 def test_marlin_24_errors(ops):
     a = torch.zeros(1, 128, dtype=torch.float16, device=DEV)
     q = torch.zeros(4, 256, dtype=torch.int32, device=DEV)

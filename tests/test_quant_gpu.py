@@ -120,6 +120,29 @@ def test_scaled_mm_tile_kernel(ops, tune, m, n, k, is_fp8, tile):
         assert torch.equal(out, ops.cutlass_scaled_mm(a, b.t(), sa, sb, out_dtype, bias))
 
 
+@pytest.mark.parametrize("m", [64, 256])
+@pytest.mark.parametrize("k,n", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+def test_scaled_mm_llama3_8b_shapes(ops, k, n, m):
+    """configs[3] (Llama-3-8B fp8 W8A8) at its own workload: the four (K, N) `bench.py --config fp8` times, default dispatch
+    (the 128 x 256 LDS-DMA tile kernel on gate_up at M = 256), per-tensor scales like Fp8LinearMethod. Checked against the
+    fp32 product on the device (test_cutlass.py:35-47's baseline and bars) on every column, against the CPU oracle on a
+    128-column slice from both ends of N, and the deferred form + materialize against the plain op bit for bit."""
+    g = torch.Generator(device=DEV)
+    g.manual_seed(m + n + k)
+    a = torch.randn(m, k, device=DEV, generator=g).to(torch.float8_e4m3fn)
+    b = torch.randn(n, k, device=DEV, generator=g).to(torch.float8_e4m3fn)
+    sa = torch.full((1, 1), 0.037, device=DEV)
+    sb = torch.full((1, 1), 0.011, device=DEV)
+    out = ops.cutlass_scaled_mm(a, b.t(), sa, sb, torch.bfloat16)
+    base = (sa * (sb * torch.mm(a.float(), b.float().t()))).to(torch.bfloat16)
+    torch.testing.assert_close(out, base, rtol=1e-2, atol=5e-2)
+    for lo in (0, n - 128):
+        orc = oracle.scaled_mm(a.cpu(), b[lo:lo + 128].cpu().t(), sa.cpu(), sb.cpu(), torch.bfloat16, None)
+        torch.testing.assert_close(out[:, lo:lo + 128].cpu().float(), orc.float(), rtol=1e-2, atol=2e-2)
+    d = ops.cutlass_scaled_mm_deferred(a, b.t(), sa, sb, torch.bfloat16)
+    assert torch.equal(d.materialize().view(torch.int16), out.view(torch.int16))  # nmx_splitk_reduce_scaled: the GEMM's own reduce
+
+
 def test_scaled_mm_errors(ops):
     a = torch.zeros(4, 32, dtype=torch.int8, device=DEV)
     b = torch.zeros(32, 16, dtype=torch.int8, device=DEV)  # row-major: must be rejected

@@ -1,7 +1,9 @@
 """GPU sanity test of the tensor-parallel path over RCCL (torch.distributed backend "nccl") with the real HIP GEMM.
-One GPU is available to the test, so world_size is 1: it exercises process-group creation on the device, the
-all-reduce / all-gather calls on device tensors and a Column -> Row parallel GPTQ-Marlin MLP end to end. The sharding
-arithmetic for world_size 2 is covered on CPU by tests/test_tp_gloo.py."""
+One GPU is available to the builder's test box, so the first tests run at world_size 1: process-group creation on the device,
+the all-reduce / all-gather calls on device tensors and a Column -> Row parallel GPTQ-Marlin MLP end to end. The two-rank legs
+(RCCL all-reduce eager + captured in a HIP graph, the one-shot xGMI all-reduce over IPC) run wherever two GPUs are visible
+(the driver's node) and FAIL there if the sum is wrong - they are skipped only for lack of a second GPU. The sharding arithmetic
+for world_size 2 is covered on CPU by tests/test_tp_gloo.py."""
 import os
 import socket
 
@@ -44,18 +46,8 @@ def test_tp_world1_rccl_mlp(ops):
         dist.all_gather_into_tensor(gat, t, group=grp)
         torch.cuda.synchronize()
         assert torch.equal(u, t) and torch.equal(gat[0], t)
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            v = t.clone()
-            dist.all_reduce(v, group=grp)
-            side.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                dist.all_reduce(v, group=grp)  # captured on the compute stream like the decode step of bench.py --tp
-            v.copy_(t * 2)
-            g.replay()
-            side.synchronize()
-        assert torch.equal(v, t * 2)
+        # (no graph-capture claim at world size 1: RCCL elides a one-rank all-reduce, the captured graph is EMPTY and a
+        # replay proves nothing - the capture of the collective is tested where two GPUs exist, test_tp2_* below)
         seed_all(0)
         H, I, G = 256, 512, 128
         cfg = GPTQMarlinConfig(4, G, False, True)
@@ -106,6 +98,7 @@ def test_bench_tp_mode_one_rank():
     r = json.loads(line)
     assert r["tp"] == 1 and r["n_gpus"] == 1 and r["scaling"] == "strong" and r["config"]["hip_graph"] is True
     assert r["allreduce"]["per_step"] == 4 and r["allreduce"]["bytes"] == 8 * 8192 * 2 and r["allreduce"]["us"] > 0
+    assert r["rccl"]["nranks"] == 1 and r["rccl"]["backend"] == "nccl"
 
 
 def _tp2_worker(rank, port, ret):
@@ -117,18 +110,39 @@ def _tp2_worker(rank, port, ret):
     import torch.distributed as dist
     from neuralmagic_vllm_amd.distributed import init_distributed_environment, tensor_model_parallel_all_reduce
     torch.cuda.set_device(rank)
+    dev = f"cuda:{rank}"
     init_distributed_environment(backend="nccl")
-    t = torch.full((256, 8192), float(rank + 1), dtype=torch.float16, device=f"cuda:{rank}")
+    res = {}
+    t = torch.full((256, 8192), float(rank + 1), dtype=torch.float16, device=dev)
     tensor_model_parallel_all_reduce(t)
     torch.cuda.synchronize()
-    ret[rank] = float(t.float().mean())
+    res["eager_mean"] = float(t.float().mean())
+    # the same call CAPTURED in a HIP graph on the compute stream (bench.py --tp, the reference's pynccl path
+    # device_communicators/pynccl.py:99-118): the replay must redo the sum on new contents of the buffer
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        v = torch.zeros(64, 8192, dtype=torch.float16, device=dev)
+        tensor_model_parallel_all_reduce(v)  # communicator warm-up outside the capture
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            w = tensor_model_parallel_all_reduce(v)
+        sums = []
+        for it in range(3):
+            v.fill_(float((rank + 1) * (it + 1)))
+            g.replay()
+            side.synchronize()
+            sums.append(float(w.float().mean()))
+    res["graph_sums"] = sums
+    ret[rank] = res
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
 def test_tp2_rccl_all_reduce_two_gpus():
-    """Two ranks, one GPU each: the [M, hidden] fp16 sum all-reduce of RowParallelLinear over RCCL / xGMI."""
+    """Two ranks, one GPU each: the [M, hidden] fp16 sum all-reduce of RowParallelLinear over RCCL / xGMI, eager AND captured
+    in a HIP graph (the replayed graph must carry the collective: a sum of fresh buffer contents on every replay)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -139,4 +153,62 @@ def test_tp2_rccl_all_reduce_two_gpus():
     for p in procs:
         p.join(240)
         assert p.exitcode == 0
-    assert ret[0] == 3.0 and ret[1] == 3.0
+    for r in range(2):
+        assert ret[r]["eager_mean"] == 3.0
+        assert ret[r]["graph_sums"] == [3.0, 6.0, 9.0], ret[r]
+
+
+def _ca2_worker(rank, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", NMX_CUSTOM_AR="1")
+    import torch.distributed as dist
+    from neuralmagic_vllm_amd.distributed.custom_all_reduce import CustomAllreduce
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    group = dist.new_group([0, 1], backend="gloo")
+    ca = CustomAllreduce(group, dev, max_size=1 << 20)
+    res = {"disabled": ca.disabled}
+    if not ca.disabled:
+        outs = []
+        for it, numel in enumerate((4096, 8 * 8192, 64 * 8192)):
+            g = torch.Generator(device=dev)
+            g.manual_seed(100 * it + rank)
+            x = torch.randn(numel, device=dev, generator=g).to(torch.float16)
+            y = ca.custom_all_reduce(x)
+            torch.cuda.synchronize()
+            ca.check()
+            # expected: both ranks' inputs summed in rank order in fp32
+            xs = []
+            for r in range(2):
+                gg = torch.Generator(device=dev)
+                gg.manual_seed(100 * it + r)
+                xs.append(torch.randn(numel, device=dev, generator=gg).to(torch.float16).float())
+            outs.append(bool(torch.equal(y, (xs[0] + xs[1]).to(torch.float16))))
+            dist.barrier()
+        res["ok"] = outs
+    ret[rank] = res
+    ca.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
+def test_custom_all_reduce_two_gpus_ipc():
+    """The one-shot xGMI all-reduce across a real device boundary: IPC handles exchanged over gloo, peer reads over xGMI, the
+    fixed-order fp32 sum identical on both ranks, no barrier timeout."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_ca2_worker, args=(r, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert ret[r]["disabled"] is False and ret[r]["ok"] == [True, True, True], ret[r]
