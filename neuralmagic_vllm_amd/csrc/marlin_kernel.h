@@ -812,7 +812,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
 #pragma unroll
           for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][t][r] += srow[t][r] * gacc[mt][t][r];
+            for (int r = 0; r < 4; ++r)  // an explicit fma: under -ffp-contract=fast hipcc fused this in one body of the pair and
+              acc[mt][t][r] = __builtin_fmaf(srow[t][r], gacc[mt][t][r], acc[mt][t][r]);  // not in the other (last-bit differences between tile shapes)
       }
       land_batch(sub + 1, have_next, lds_a + (PAR ^ 1) * ABUF, std::integral_constant<int, PAR ^ 1>{});
       sync_slice();
@@ -1326,7 +1327,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
         for (int t = 0; t < 4; ++t) {
           const float sv = Scalar<scalar_t>::to_f32(raw.e[t]) * keep;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt][t][r] += sv * gacc[mt][t][r];
+          for (int mt = 0; mt < MT; ++mt) acc[mt][t][r] = __builtin_fmaf(sv, gacc[mt][t][r], acc[mt][t][r]);
         }
       }
       load_scales(next, U);
@@ -1334,7 +1335,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[mt][t] += gacc[mt][t] * keep;
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][t][r] = __builtin_fmaf(gacc[mt][t][r], keep, acc[mt][t][r]);
     }
   };
 
@@ -1762,6 +1765,23 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
     if (plain) {
       const DecodeCfg dc = pick_decode_cfg(p.M, p.N, p.K);
       if (dc.nw != 0) return launch_decode<scalar_t>(p, dc, scratch, scratch_bytes, stream);
+    }
+  }
+  if constexpr (!SP && KIND == W_INT4) {
+    // 64 < M, fp16, plain layout: both operands by LDS-DMA (marlin_dma.hip)
+    int dsplits = 1;
+    if (p.perm == nullptr && !p.slow_act_order &&
+        nmx_dma_pick(p.M, p.N, p.K, p.num_groups, p.group_size, KIND, __is_same(scalar_t, bf16) ? 1 : 0, &dsplits)) {
+      NmxWideCall call;
+      call.a = p.a; call.b = p.b; call.scales = p.scales; call.c = p.c; call.scratch = scratch; call.scratch_bytes = scratch_bytes;
+      call.M = p.M; call.N = p.N; call.K = p.K; call.num_groups = p.num_groups; call.group_size = p.group_size;
+      call.kind = KIND; call.is_bf16 = 0;
+      call.defer_reduce = p.defer_reduce;
+      call.act_out = p.act_out;
+      const int rc = nmx_dma_run(call, dsplits, stream);
+      p.k_splits = call.splits_done;
+      p.act_done = call.act_done;
+      return rc;
     }
   }
   if constexpr (!SP) {

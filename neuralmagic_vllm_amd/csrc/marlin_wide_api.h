@@ -27,3 +27,9 @@ struct NmxWideCfg { int wm, wn, wk, splits, mt; };  // mt = 16-row tiles per wav
 // true when the wide kernel handles this problem (M large enough, plain layout); fills the configuration
 __attribute__((visibility("hidden"))) bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg, int kind = 0);  // kind: WeightKind (0 = int4)
 __attribute__((visibility("hidden"))) int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream);
+
+// marlin_dma_kernel (marlin_dma.hip): fp16 int4 GEMM with both operands delivered by LDS-DMA. nmx_dma_pick: true when it
+// should serve this problem (NMX_GEMM_DMA=0 disables it, =N forces it with N K splits); nmx_dma_run launches it (+ the
+// split-K reduce unless call.defer_reduce) and fills call.splits_done / call.act_done.
+__attribute__((visibility("hidden"))) bool nmx_dma_pick(int M, int N, int K, int num_groups, int group_size, int kind, int is_bf16, int* splits);
+__attribute__((visibility("hidden"))) int nmx_dma_run(NmxWideCall& call, int splits, hipStream_t stream);

@@ -15,7 +15,10 @@ def main():
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
     from neuralmagic_vllm_amd import _custom_ops as ops
     from neuralmagic_vllm_amd import _lib
-    if cfg.startswith("W:"):
+    if cfg.startswith("X:"):
+        _lib.set_tuning("NMX_GEMM_DMA", cfg[2:])
+    elif cfg.startswith("W:"):
+        _lib.set_tuning("NMX_GEMM_DMA", "0")
         _lib.set_tuning("NMX_GEMM_WIDE", cfg[2:])
     elif cfg != "auto":
         _lib.set_tuning("NMX_GEMM_WIDE", "0")

@@ -3,7 +3,8 @@ weight tensors captured in a HIP graph (dependent-launch boundaries included, no
 configuration against the default path of the skinny kernel on the same inputs.
 
 usage (GPU box): python3 tools/lean_sweep.py [M ...] > gpurun_out/lean_sweep.txt
-cfg strings: "D:auto" = default dispatch, "L:nw,splits[,mt[,ws]]" = marlin_decode_kernel, "G:ngrp" = marlin_large_kernel, "S:mt,ng,splits[,w8]" = marlin_gemm_kernel, "S:auto" its heuristic."""
+cfg strings: "D:auto" = default dispatch, "L:nw,splits[,mt[,ws]]" = marlin_decode_kernel, "G:ngrp" = marlin_large_kernel, "S:mt,ng,splits[,w8]" = marlin_gemm_kernel, "S:auto" its heuristic,
+"X:splits" = marlin_dma_kernel."""
 import os
 import sys
 
@@ -19,11 +20,15 @@ dev = "cuda:0"
 
 def set_cfg(cfg):
     from neuralmagic_vllm_amd import _lib
-    for k in ("NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP", "NMX_GEMM_WIDE"):
+    for k in ("NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP", "NMX_GEMM_WIDE", "NMX_GEMM_DMA"):
         _lib.set_tuning(k, None)
     kind, val = cfg.split(":")
     if kind == "D":  # default dispatch, no override
         return
+    if kind == "X":  # marlin_dma_kernel with val K splits
+        _lib.set_tuning("NMX_GEMM_DMA", val)
+        return
+    _lib.set_tuning("NMX_GEMM_DMA", "0")
     if kind == "W":  # wide kernel "wm,wn,splits"
         _lib.set_tuning("NMX_GEMM_WIDE", val)
         return
@@ -89,7 +94,10 @@ def main():
     g.manual_seed(0)
     e = torch.empty(0, dtype=torch.int32, device=dev)
     wsp = torch.zeros(28672 // 64 * 16, dtype=torch.int32, device=dev)
+    only_shapes = os.environ.get("LEAN_SWEEP_SHAPES")
     for name, (K, N) in SHAPES.items():
+        if only_shapes and name not in only_shapes.split(","):
+            continue
         ws = [(torch.randint(-2**31, 2**31 - 1, (K // 16, N * 2), dtype=torch.int32, device=dev, generator=g),
                (torch.rand(K // 128, N, device=dev, generator=g) * 0.004 + 0.002).half()) for _ in range(NL)]
         for M in Ms:
@@ -116,7 +124,10 @@ def main():
                                 ops.gptq_marlin_gemm(x, w[0], w[1], e, e, wsp, 4, M, N, K, True)
 
                     us = time_graph(run) / NL
-                    print(f"{name:8} M={M:4d} {cfg:12} {us:7.2f} us  {by / us / 1e3:7.0f} GB/s  {2.0 * M * K * N / us / 1e6:7.1f} TFLOP/s  relerr_vs_default={err:.2e}", flush=True)
+                    from neuralmagic_vllm_amd import _lib as _l
+                    if hasattr(_l.lib(), "nmx_dma_dbg_dump"):
+                        _l.lib().nmx_dma_dbg_dump()
+                    print(f"{os.environ.get('NMX_LIB_PATH', '').split('/')[-1]:18} {name:8} M={M:4d} {cfg:12} {us:7.2f} us  {by / us / 1e3:7.0f} GB/s  {2.0 * M * K * N / us / 1e6:7.1f} TFLOP/s  relerr_vs_default={err:.2e}", flush=True)
                 except Exception as ex:  # noqa: BLE001
                     print(f"{name:8} M={M:3d} {cfg:12} FAILED {ex}", flush=True)
                     torch.cuda.synchronize()
