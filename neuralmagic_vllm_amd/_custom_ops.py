@@ -64,39 +64,26 @@ def is_custom_op_supported(op_name: str) -> bool:
 
 
 # ---------------------------------------------------------------------------------------------------------
-# scratch for split-K partial sums (owned here, allocated outside graph capture, reused by every call)
+# scratch for split-K partial sums
 # ---------------------------------------------------------------------------------------------------------
-# One buffer per (device, stream): kernels on two streams never share partial sums. A buffer that has been handed out is
-# NEVER freed: a captured HIP graph has its address baked in, so when a later eager call needs more bytes the old buffer
-# is retired (kept alive in _retired) and a larger one takes its place for new calls - replaying an old graph still
-# writes into memory that belongs to nobody else.
-_scratch = {}
-_retired = []
-_SCRATCH_FLOOR = 64 << 20
-
-
+# Round 3: the scratch of a call is a plain torch allocation of exactly the bytes the dispatch can use
+# (nmx_*_scratch_bytes; 0 for launches without a K split), made on the calling stream and dropped when the last user drops
+# it: the GEMM + reduce launches of a plain op, or the DeferredGemm whose `partial` is a view of it. torch's caching allocator
+# hands a freed block out again only to later work of the SAME stream, and inside torch.cuda.graph capture the block comes
+# from the graph's private pool and lives as long as the graph - so nothing is pinned per (device, stream) any more (rounds
+# 1-2 kept >= 64 MiB per stream forever and let a capture borrow another stream's buffer), two streams never share slabs,
+# and a DeferredGemm can no longer be invalidated by a later GEMM on its stream: it owns its slabs.
 def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
-    index = device.index if device.index is not None else torch.cuda.current_device()
-    key = (index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _scratch.get(key)
-    if buf is None or buf.numel() < nbytes:
-        if torch.cuda.is_current_stream_capturing():
-            # capture streams are private to the capture: fall back to the device's largest buffer of any stream
-            cands = [b for (i, _), b in _scratch.items() if i == index]
-            if not cands:
-                raise RuntimeError("nmx: GEMM scratch must be allocated before graph capture "
-                                   "(run one eager call, or reserve_scratch(), first)")
-            return max(cands, key=lambda b: b.numel())  # the C side degrades to the K splits that fit
-        if buf is not None:
-            _retired.append(buf)
-        buf = torch.empty(max(nbytes, _SCRATCH_FLOOR), dtype=torch.uint8, device=device)
-        _scratch[key] = buf
-    return buf
+    return torch.empty(max(int(nbytes), 0), dtype=torch.uint8, device=device)
 
 
-def reserve_scratch(device, nbytes: int = _SCRATCH_FLOOR) -> None:
-    """Sizes the calling stream's split-K scratch once (e.g. for the largest prefill shape) before graphs are captured."""
-    _get_scratch(torch.device(device), int(nbytes))
+def reserve_scratch(device, nbytes: int = 0) -> None:
+    """Kept for callers of rounds 1-2 (nothing to reserve: the scratch is allocated per call, see above)."""
+
+
+def release_scratch(device=None) -> None:
+    """Returns the cached, currently unused blocks of torch's allocator (where freed scratch lives) to the device."""
+    torch.cuda.empty_cache()
 
 
 # ---------------------------------------------------------------------------------------------------------

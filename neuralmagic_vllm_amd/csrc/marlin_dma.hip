@@ -485,6 +485,7 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
     return;
   }
   if (kg != 0 || !col_ok) return;
+  if constexpr ((NMX_DABLATE & 8192) != 0) { if (acc[0][0][0] != 12345.678f) return; }  // no output stores (the K-group reduce stays)
   // lane (g, li): D rows = the 4 consecutive output columns 16 t + 4 g + r, D col = activation row li
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
@@ -512,6 +513,353 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
 #endif
 }
 
+
+// ---- producer / consumer form (round 3, late) -----------------------------------------------------------------------------
+// marlin_dma_kernel's valid timing ablations (tools/dma_ablate.sh) showed its cost classes ADD: skeleton
+// (LDS reads, barrier, waits) + conversion VALU + MFMA + DMA issue, ~4.2 instructions per MFMA in every wave, and two waves
+// of the SAME program on a SIMD overlap their MFMA and VALU phases only by accident. A SIMD co-issues an MFMA and a VALU
+// instruction only from DIFFERENT waves - so here the two waves of a SIMD are different programs:
+//   * waves 0..3 (CONSUMERS, one per SIMD; wave wn owns the 128 x 64 tile of column group wn over the WHOLE K range of the
+//     workgroup) run no conversion at all: per 64-k stage 16 activation-fragment reads + 8 weight-fragment reads
+//     (ds_read_b128) + 64 MFMAs, and they issue the stage's four activation DMAs of their row quarter;
+//   * waves 4..7 (PRODUCERS, the other wave of each SIMD; wave wn serves column group wn) DMA the packed words + scales,
+//     read them back one stage later, run the whole int4 -> fp16 conversion (112 VALU per stage) and park the eight MFMA A
+//     fragments of the NEXT stage in an LDS fragment buffer in consumer lane order (8 ds_write_b128, linear: no conflicts).
+// One barrier per stage; ring of three stage slots (activations + packed words), two fragment buffers. No K-groups inside the
+// workgroup (the consumers walk all of its stages), so no LDS reduction in the epilogue; cross-workgroup K splits as before.
+constexpr int kFBuf = kWN * 8 * 64 * 16;      // [column group][fragment 4 p + t][lane] x 16 B = 32 KiB
+
+#if (NMX_DABLATE & 65536)
+#define PC_MMA(c, a, b) (c)[0] += __builtin_bit_cast(float, (a)[1] ^ (b)[2])
+#else
+#define PC_MMA(c, a, b) a_mfma_f16(c, a, b)
+#endif
+template <bool SCALED>
+__global__ __launch_bounds__(512, 2) void marlin_pc_kernel(const DmaParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave & (kWN - 1);
+  const bool producer = wave >= kWN;
+  const int g = lane >> 4, li = lane & 15, hb = (lane >> 3) & 1, c8 = lane & 7;
+  const int N = p.N, K = p.K, M = p.M;
+
+  const int m_blocks = (M + kBM - 1) / kBM;
+  int tile_x, block_m, split_id;
+  if (p.xcd_split && (p.k_splits == 2 || p.k_splits == 4 || p.k_splits == 8)) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int per_split = 8 / p.k_splits;
+    const int q = lin >> 3;
+    split_id = (lin & 7) / per_split;
+    block_m = q % m_blocks;
+    tile_x = (q / m_blocks) * per_split + (lin & 7) % per_split;
+  } else {
+    const int bx_group = blockIdx.x / (8 * m_blocks), bx_r = blockIdx.x % (8 * m_blocks);
+    tile_x = bx_group * 8 + (bx_r & 7);
+    block_m = bx_r >> 3;
+    split_id = blockIdx.y;
+  }
+  if (tile_x * kWN * 64 >= N) return;  // padding workgroup
+  const bool fuse_act = p.act_out != nullptr;
+  const int n0 = fuse_act ? (wn >= kWN / 2 ? N / 2 : 0) + (tile_x * (kWN / 2) + (wn % (kWN / 2))) * 64 : (tile_x * kWN + wn) * 64;
+  const bool col_ok = n0 < N;
+  const int nl = col_ok ? n0 : 0;
+  const int m0 = block_m * kBM;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const fbuf = smem + kNBUF * kSlot;
+
+  const int total_stages = K / 64;
+  const int per = (total_stages + p.k_splits - 1) / p.k_splits;
+  const int st_begin = min(split_id * per, total_stages), st_end = min(st_begin + per, total_stages);
+  const int nst = st_end - st_begin;
+  const int st_last = min(st_begin + max(nst - 1, 0), total_stages - 1);
+
+  const int row_bytes = N * 8;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, M * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.b), 0, (K / 16) * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.scales), 0, p.num_groups * N * 2, 0x00020000);
+  int a_voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 8 * (4 * wn + j) + (lane >> 3);
+    a_voff[j] = (min(m0 + r, M - 1) * K + 8 * ((lane & 7) ^ a_swz(r))) * 2;
+  }
+  const int w_voff = ((lane >> 3) & 1) * row_bytes + (nl / 64) * 512 + (4 * (lane & 7) + (lane >> 4)) * 16;
+  const int s_voff = (nl + 2 * (lane & 31)) * 2;
+  const int gs_shift = SCALED ? (31 - __builtin_clz((unsigned)max(p.group_size / 64, 1))) : 0;
+  constexpr int NW = 2 + (SCALED ? 1 : 0);  // producer DMA instructions per stage (consumers: 4)
+
+  auto issue_a1 = [&](auto j_c, auto sa_c, int rel) {  // consumer: activation DMA j of walk position rel into slot SA
+    constexpr int J = decltype(j_c)::value, SA = decltype(sa_c)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = min(st_begin + rel, st_last);
+    auto* da = (__attribute__((address_space(3))) char*)(ring + SA * kSlot + (4 * wn + J) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, da, 16, a_voff[J], sa * 128, 0, 0);
+#endif
+  };
+  auto issue_a = [&](auto sa_c, int rel) {
+    issue_a1(std::integral_constant<int, 0>{}, sa_c, rel);
+    issue_a1(std::integral_constant<int, 1>{}, sa_c, rel);
+    issue_a1(std::integral_constant<int, 2>{}, sa_c, rel);
+    issue_a1(std::integral_constant<int, 3>{}, sa_c, rel);
+  };
+  auto issue_w = [&](auto sw_c, int rel) {  // producer: packed words (+ scales) of walk position rel into slot SW
+    constexpr int SW = decltype(sw_c)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sw = min(st_begin + rel, st_last);
+    auto* dw = (__attribute__((address_space(3))) char*)(ring + SW * kSlot + kAImg + wn * 2048);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dw, 16, w_voff, (4 * sw) * row_bytes, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dw + 1024, 16, w_voff, (4 * sw + 2) * row_bytes, 0, 0);
+    if constexpr (SCALED) {
+      const int grp = min(sw >> gs_shift, p.num_groups - 1);
+      auto* ds = (__attribute__((address_space(3))) char*)(ring + SW * kSlot + kAImg + kWImg + wn * 256);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, ds, 4, s_voff, grp * N * 2, 0, 0);
+    }
+#endif
+  };
+
+  const int a_rd0 = li * 128 + (((2 * g) ^ a_swz(li)) * 16), a_rd1 = li * 128 + (((2 * g + 1) ^ a_swz(li)) * 16);
+  const int w_rd = kAImg + wn * 2048 + (g >> 1) * 1024 + ((g & 1) * 8 + c8) * 16;
+  const int s_rd = kAImg + kWImg + wn * 256 + c8 * 16;
+  const int f_off = (wn * 8 * 64 + lane) * 16;  // this lane's 16 bytes of fragment 0 of its column group; fragment f at + 1024 f
+
+  const uint32_t magic = 0x64006400u, neg72 = 0xd480d480u;
+  const uint32_t shv = 8u * (uint32_t)hb;
+  const uint32_t ssel = hb ? 0x03020302u : 0x01000100u;
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  // ---- producer: packed words of ring slot SLOT -> the 8 fp16 fragments of that stage in fragment buffer fb ----
+  auto produce = [&](auto slot_c, char* fb) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    const char* buf = ring + SLOT * kSlot;
+    uint32_t s2[4] = {0, 0, 0, 0};
+    if constexpr (SCALED) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(buf + s_rd);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s2[t] = __builtin_amdgcn_perm(v[t], v[t], ssel);
+    }
+    uint32_t raw[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(buf + w_rd + 256 * m);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) raw[m][t] = v[t] >> shv;
+    }
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint32_t w[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if constexpr ((NMX_DABLATE & 16384) != 0) { w[m] = raw[m][t] ^ s2[t]; continue; }  // ablation: no conversion
+          a_and_or(w[m], raw[m][t], pp == 0 ? 0x000f000fu : 0x00f000f0u, magic);
+          if (pp == 0) a_pk_add(w[m], 0xe408e408u);          // (1024 + q) - 1032
+          else a_pk_fma(w[m], 0x2c002c00u, neg72);           // (1024 + 16 q) / 16 - 72
+          if constexpr (SCALED) a_pk_mul(w[m], s2[t]);
+        }
+        *reinterpret_cast<u32x4*>(fb + f_off + (4 * pp + t) * 1024) = u32x4{w[0], w[1], w[2], w[3]};
+      }
+    }
+  };
+
+  // ---- producers: their own loop (same barrier count as the consumers'), then out through the epilogue's barriers ----
+  if (producer) {
+    issue_w(I0{}, 0);
+    issue_w(I1{}, 1);
+    issue_w(I2{}, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");  // this wave's own DMA of stage 0
+    produce(I0{}, fbuf);
+    auto pbody = [&](auto cur_c, int it) {
+      constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % kNBUF;
+      // the fragments of stage it are written (lgkmcnt), the packed words of it + 1 have landed (this wave's own DMA)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_w(std::integral_constant<int, CUR>{}, it + 3);  // this slot's packed words were converted last iteration
+      produce(std::integral_constant<int, NXT>{}, fbuf + ((it + 1) & 1) * kFBuf);
+    };
+    for (int it = 0; it < per; it += 3) {
+      pbody(I0{}, it);
+      if (it + 1 >= per) break;
+      pbody(I1{}, it + 1);
+      if (it + 2 >= per) break;
+      pbody(I2{}, it + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (fuse_act) __syncthreads();
+    return;
+  }
+
+  // ---- consumers ----
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue_a(I0{}, 0);
+  issue_a(I1{}, 1);
+
+  // Software pipeline across the barrier: the first fragment reads of a stage can only be issued behind its barrier, and with
+  // ONE consumer wave per SIMD nothing else feeds the matrix pipe meanwhile - so the last two MFMA rows of pass 1 of every
+  // stage are held back (operands stay in registers: t_af, t_wq) and run behind the NEXT stage's barrier, right after that
+  // stage's first eight fragment reads have been issued. Pass 1's weight fragments are read during pass 0.
+  u32x4 t_af[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+  u32x4 t_wq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+  auto tail = [&]() {  // rows 6, 7 of pass 1 of the previous stage (zeros before the first stage: adds nothing)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) PC_MMA(acc[6][t], t_wq[t], t_af[0]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) PC_MMA(acc[7][t], t_wq[t], t_af[1]);
+  };
+  auto body = [&](auto cur_c, int it) {
+    constexpr int CUR = decltype(cur_c)::value, PRV = (CUR + 2) % kNBUF;
+    // the activation rows of stage it this wave issued have landed; behind the barrier everybody's rows and the producers'
+    // fragments of stage it are visible
+    if constexpr ((NMX_DABLATE & 32768) == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* const fb_cur = fbuf + (it & 1) * kFBuf;
+    const char* const buf = ring + CUR * kSlot;
+    if (it >= nst) {  // out of stages (uneven split): keep the DMA / barrier pattern; flush the held-back rows once
+      issue_a(std::integral_constant<int, PRV>{}, it + 2);
+      tail();
+      t_af[0] = u32x4{0, 0, 0, 0};
+      t_af[1] = u32x4{0, 0, 0, 0};
+      return;
+    }
+    u32x4 af[12];
+    u32x4 wq[4], wq1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wq[t] = *reinterpret_cast<const u32x4*>(fb_cur + f_off + t * 1024);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const u32x4*>(buf + a_rd0 + mt * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    tail();
+    __builtin_amdgcn_sched_barrier(0);
+    auto pass0 = [&](auto self, auto mt_c) {
+      constexpr int mt = decltype(mt_c)::value;
+      if constexpr (mt < 8) {
+        PC_MMA(acc[mt][0], wq[0], af[mt]);
+        PC_MMA(acc[mt][1], wq[1], af[mt]);
+        PC_MMA(acc[mt][2], wq[2], af[mt]);
+        PC_MMA(acc[mt][3], wq[3], af[mt]);
+        if constexpr (mt + 4 < 8) af[mt + 4] = *reinterpret_cast<const u32x4*>(buf + a_rd0 + (mt + 4) * 2048);
+        else af[8 + (mt - 4)] = *reinterpret_cast<const u32x4*>(buf + a_rd1 + (mt - 4) * 2048);
+        if constexpr (mt < 4) wq1[mt] = *reinterpret_cast<const u32x4*>(fb_cur + f_off + (4 + mt) * 1024);  // pass 1's weight fragments
+        __builtin_amdgcn_sched_barrier(0);  // the fragment reads stay 4 rows ahead of their MFMAs (hoisted to the top they spill)
+        if constexpr ((mt & 1) == 0 && (NMX_DABLATE & 32768) == 0) {  // the four activation DMAs of stage it + 2, one behind every second MFMA row
+          issue_a1(std::integral_constant<int, (mt >> 1)>{}, std::integral_constant<int, PRV>{}, it + 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        self(self, std::integral_constant<int, mt + 1>{});
+      }
+    };
+    pass0(pass0, std::integral_constant<int, 0>{});
+    auto pass1 = [&](auto self, auto mt_c) {
+      constexpr int mt = decltype(mt_c)::value;
+      if constexpr (mt < 6) {  // rows 6, 7 are held back (tail)
+        constexpr int ai = mt < 4 ? 8 + mt : mt;
+        PC_MMA(acc[mt][0], wq1[0], af[ai]);
+        PC_MMA(acc[mt][1], wq1[1], af[ai]);
+        PC_MMA(acc[mt][2], wq1[2], af[ai]);
+        PC_MMA(acc[mt][3], wq1[3], af[ai]);
+        if constexpr (mt + 4 < 8) af[mt + 4] = *reinterpret_cast<const u32x4*>(buf + a_rd1 + (mt + 4) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+        self(self, std::integral_constant<int, mt + 1>{});
+      }
+    };
+    pass1(pass1, std::integral_constant<int, 0>{});
+    t_af[0] = af[6];
+    t_af[1] = af[7];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) t_wq[t] = wq1[t];
+  };
+  for (int it = 0; it < per; it += 3) {
+    body(I0{}, it);
+    if (it + 1 >= per) break;
+    body(I1{}, it + 1);
+    if (it + 2 >= per) break;
+    body(I2{}, it + 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  tail();  // the last stage's held-back rows
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) asm volatile("s_nop 7" : "+v"(acc[mt][0]), "+v"(acc[mt][1]), "+v"(acc[mt][2]), "+v"(acc[mt][3]));
+  __syncthreads();  // nothing lands in LDS any more; the ring is free for the epilogue
+
+  if constexpr (!SCALED) {
+    {
+      const f16* sc = reinterpret_cast<const f16*>(p.scales) + nl;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = 16 * t + 4 * g + r;
+          const int cc = col & 7, bb = col >> 3;
+          const float sv = (float)sc[32 * (bb >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (bb & 3)];
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {
+            acc[mt][t][r] *= sv;
+            asm volatile("" : "+v"(acc[mt][t][r]));
+          }
+        }
+    }
+  }
+  if (fuse_act) {
+    constexpr int HW = kWN / 2;
+    u32x2* ex = reinterpret_cast<u32x2*>(smem);
+    const int pair = (wn % HW) * (32 * 64);
+    if (wn >= HW) {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          union { f16 h[4]; u32x2 u; } r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
+          ex[pair + (mt * 4 + t) * 64 + lane] = r.u;
+        }
+    }
+    __syncthreads();
+    if (wn >= HW || !col_ok) return;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + mt * 16 + li;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        union { f16 h[4]; u32x2 u; } up, o;
+        up.u = ex[pair + (mt * 4 + t) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.h[j] = rnd_mul<f16>(silu_rnd<f16>((f16)acc[mt][t][j]), up.h[j]);
+        if (m < M) *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.act_out) + (int64_t)m * (N / 2) + n0 + 16 * t + 4 * g) = o.u;
+      }
+    }
+    return;
+  }
+  if (!col_ok) return;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + mt * 16 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = n0 + 16 * t + 4 * g;
+      if (p.k_splits == 1) {
+        union { f16 h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
+        *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.c) + (int64_t)m * N + n) = r.u;
+      } else {
+        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // One launch of marlin_dma_kernel with `splits` K splits across workgroups (the caller has sized the scratch). The split-K
@@ -527,8 +875,25 @@ static int nmx_dma_launch(NmxWideCall& call, int splits, int xcd_split, hipStrea
   const size_t red = (size_t)kWN * 32 * 64 * 4 * sizeof(float);
   const size_t smem = std::max(ring, red);
   dim3 grid(ceil_div(ceil_div(p.N, 64 * kWN), 8) * 8 * ceil_div(p.M, kBM), splits, 1);
-  bool ls = false;  // NMX_GEMM_DMA = "splits,1": the loader / consumer split
-  if (const char* e = nmx_tune(NMX_TUNE_GEMM_DMA)) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) ls = b != 0; }
+  bool ls = false;  // NMX_GEMM_DMA = "splits,1": the loader / consumer split; "splits,2": marlin_pc_kernel
+  int mode = 0;
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_DMA)) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) mode = b; }
+  ls = mode == 1;
+  if (mode == 2) {
+    const size_t pc_smem = (size_t)kNBUF * kSlot + 2 * kFBuf;
+    if (call.num_groups > 1) {
+      auto kern = marlin_pc_kernel<true>;
+      NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_smem));
+      kern<<<grid, 512, pc_smem, stream>>>(p);
+    } else {
+      auto kern = marlin_pc_kernel<false>;
+      NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_smem));
+      kern<<<grid, 512, pc_smem, stream>>>(p);
+    }
+    NMX_LAUNCH_CHECK();
+    call.splits_done = splits;
+    return NMX_OK;
+  }
 #define NMX_DMA_LAUNCH(SC, LSV)                                                                                                   \
   {                                                                                                                               \
     auto kern = marlin_dma_kernel<SC, LSV>;                                                                                       \
@@ -592,10 +957,27 @@ bool nmx_dma_pick(int M, int N, int K, int num_groups, int group_size, int kind,
   int sp = 1;
   if (forced > 0) {
     sp = forced;
-  } else {
-    return false;  // default rule: see below once measured
+    while (sp > 1 && stages / (sp * kWK) < 2) sp /= 2;  // at least two stages per K-group
+    *splits = sp;
+    return true;
   }
-  while (sp > 1 && stages / (sp * kWK) < 2) sp /= 2;  // at least two stages per K-group
+  // Default rule, from tools/lean_sweep.py (32-launch graph chains over distinct weights, deferred reduce; gpurun_out/
+  // dma_sweep_s*.txt, M = 128 .. 2048 on the four Llama-3-8B shapes): the kernel runs where its 128 x 256 tiles times 1 / 2 / 4 /
+  // 8 K splits give 160 .. 256 workgroups with >= 8 stages per K-group - there it is 8-16 % faster than marlin_wide_kernel /
+  // the 64-row tiles on the matrices that need K splits (down at M = 256: 35.4 vs 38.6-41.6 us, qkv at M = 512: 37.1 vs 44.4, o at
+  // M = 512 / 1024: 26.0 / 39.7 vs 28.8 / 45.8, down at M = 512: 59.4 vs 68.3) and level (+-2 %) where the tiles alone fill the
+  // chip (gate_up from M = 256, everything at M = 2048). One row block (M <= 128) and short K per split (o at M = 256: 8
+  // splits x 4 stages 18.3-19.4 vs 17.3-18.8 us) stay with the older kernels.
+  if (M <= 128) return false;
+  // batch <= 256 of the decode step: only the long-K matrices. In the step the slabs of a K split are summed by the consumer op,
+  // so MORE splits than the older dispatch takes cost there what they save here (bench.py A/B at batch 256 with qkv on 4
+  // splits instead of 2: step 11.15 vs 11.09 ms); down_proj runs 8 splits either way and is 8-10 % faster on this kernel.
+  if (M <= 256 && K < 8192) return false;
+  // an explicit override of one of the older kernels (sweeps, their tests) keeps this one out of the way
+  if (nmx_tune(NMX_TUNE_GEMM_WIDE) != nullptr || nmx_tune(NMX_TUNE_GEMM_CFG) != nullptr || nmx_tune(NMX_TUNE_GEMM_LARGE) != nullptr) return false;
+  const int tiles = ceil_div(N, 64 * kWN) * ceil_div(M, kBM);
+  while (sp < 8 && tiles * sp * 2 <= 256 && stages / (sp * 2 * kWK) >= 8) sp *= 2;
+  if (tiles * sp < 160) return false;
   *splits = sp;
   return true;
 }

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 2) void marlin_gemm_kernel(const Ge
   // (2:4: q0 = the k-tile row's words, q1 = the lane's 8 metadata int16: tile x = 2 p + q, k-half cc at 4 p + 2 cc + q)
   using bvec_t = typename std::conditional<I4, u32x2, u32x4>::type;
   using mvec_t = typename std::conditional<SP, u32x4, bvec_t>::type;
-  // X4: dense int4, hand-counted loop - ONE 16-byte load per lane and k-step (chunk 4 c8 + g of k-tile 2 ks + hi, all
+  // X4: dense int4, fixed-pattern loop - ONE 16-byte load per lane and k-step (chunk 4 c8 + g of k-tile 2 ks + hi, all
   // four words) instead of two 8-byte ones; split_pair() trades the unused half with lane ^ 8. A CU retires about
   // one vector-memory wave instruction per ~38 cycles whatever its width, so 1 KiB instead of 512 B per instruction
   // is what lifts the per-CU weight rate.

@@ -35,7 +35,7 @@ def run(ops, a, packed, s, M, N, K, group):
     return mq, ms, e, ws
 
 
-@pytest.mark.parametrize("splits", ["1", "2", "4", "1,1", "2,1"])  # "s,1": loader / consumer split of the workgroup
+@pytest.mark.parametrize("splits", ["1", "2", "4", "1,1", "2,1", "1,2", "2,2", "4,2"])  # "s,1": loader / consumer split; "s,2": marlin_pc_kernel
 @pytest.mark.parametrize("group", [128, 64, -1])
 @pytest.mark.parametrize("M,N,K", [(128, 256, 256), (70, 320, 512), (130, 512, 448), (256, 1024, 1024), (300, 192, 2048),
                                    (1, 64, 128), (257, 4096, 896)])
@@ -60,13 +60,14 @@ def test_dma_kernel_shapes(ops, tune, M, N, K, group, splits):
     assert compute_max_diff(out.float().cpu(), base.float().cpu()) < TOL
 
 
+@pytest.mark.parametrize("mode", ["1", "1,2"])
 @pytest.mark.parametrize("group", [128, -1])
 @pytest.mark.parametrize("M,N,K", [(128, 512, 256), (200, 1024, 512), (256, 3072, 1024)])
-def test_dma_fused_silu_and_mul(ops, tune, M, N, K, group):
+def test_dma_fused_silu_and_mul(ops, tune, M, N, K, group, mode):
     """gate | up column groups in one workgroup + the activation in the epilogue: the same bits as GEMM + silu_and_mul."""
     a, packed, s, w_ref = make(M, N, K, group, 7 * M + N + K)
     mq, ms, e, ws = run(ops, a, packed, s, M, N, K, group)
-    tune(NMX_GEMM_DMA="1")
+    tune(NMX_GEMM_DMA=mode)
     out = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, M, N, K, True)
     two = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
     ops.silu_and_mul(two, out)
@@ -76,7 +77,8 @@ def test_dma_fused_silu_and_mul(ops, tune, M, N, K, group):
 
 
 @pytest.mark.parametrize("M", [128, 256])
-@pytest.mark.parametrize("K,N,splits", [(4096, 6144, 4), (4096, 4096, 8), (4096, 28672, 1), (14336, 4096, 8)])
+@pytest.mark.parametrize("K,N,splits", [(4096, 6144, "4"), (4096, 4096, "8"), (4096, 28672, "1"), (14336, 4096, "8"),
+                                        (4096, 6144, "4,2"), (4096, 28672, "1,2"), (14336, 4096, "8,2")])
 def test_dma_llama3_8b_shapes_vs_oracle(ops, tune, K, N, M, splits):
     """The four Llama-3-8B (K, N) on the DMA kernel against the CPU oracle on a 128-column slice from both ends of N."""
     seed_all(K + N + M)

@@ -166,3 +166,43 @@ def test_forward_prefix_shim_and_errors(ops):
         context_attention_fwd(z, z, z, z.clone(), torch.zeros(4, 2, 3, 16, 8, dtype=torch.float16, device=DEV),
                               torch.zeros(4, 2, 24, 16, dtype=torch.float16, device=DEV), g["b_loc"][:1], g["b_start_loc"][:1],
                               g["b_seq_len"][:1], g["b_ctx_len"][:1], 4)
+
+
+@pytest.mark.parametrize("heads", [(32, 8), (8, 8), (8, 1)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_plain_prefill_shim_ctx0(ops, heads, dtype):
+    """ROCmFlashAttentionImpl's prefix-free prefill (rocm_flash_attn.py:359-394) through the shims of
+    attention/ops/triton_flash_attention.py: `triton_attention` / `flash_attn_varlen_func` signatures on nmx_context_attention_fwd
+    with an empty paged context; checked against the CPU oracle and the fp32 torch restatement (causal, GQA / MQA)."""
+    from neuralmagic_vllm_amd.attention.ops.triton_flash_attention import flash_attn_varlen_func, triton_attention
+    seed_all(11)
+    H, Hkv = heads
+    D = 128
+    lens = [1, 37, 300, 64, 129]
+    T = sum(lens)
+    q = torch.empty(T, H, D).uniform_(-1, 1).to(dtype)
+    k = torch.empty(T, Hkv, D).uniform_(-1, 1).to(dtype)
+    v = torch.empty(T, Hkv, D).uniform_(-1, 1).to(dtype)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    out, aux = triton_attention(q.to(DEV), k.to(DEV), v.to(DEV), None, cu.to(DEV), cu.to(DEV), max(lens), max(lens), True, D**-0.5, None)
+    assert aux is None
+    # expected value: the same problem as a contexted prefill with ctx = 0
+    kc = torch.zeros(1, Hkv, D // 8, 16, 8, dtype=dtype)
+    vc = torch.zeros(1, Hkv, D, 16, dtype=dtype)
+    b_loc = torch.zeros(len(lens), 1, dtype=torch.int32)
+    sl = torch.tensor(lens, dtype=torch.int32)
+    ctx = torch.zeros(len(lens), dtype=torch.int32)
+    ref = ref_prefix_prefill(q, k, v, kc, vc, b_loc, cu[:-1], sl, ctx)
+    tol = dict(atol=2e-3, rtol=2e-3) if dtype == torch.float16 else dict(atol=1.5e-2, rtol=1.5e-2)
+    torch.testing.assert_close(out.cpu().float(), ref, **tol)
+    orc = torch.zeros_like(q)
+    oracle.context_attention_fwd(q, k, v, orc, kc, vc, b_loc, cu[:-1].contiguous(), sl, ctx, max(lens), None, None)
+    torch.testing.assert_close(out.cpu().float(), orc.float(), **tol)
+    out2 = flash_attn_varlen_func(q.to(DEV), k.to(DEV), v.to(DEV), cu_seqlens_q=cu.to(DEV), cu_seqlens_k=cu.to(DEV), max_seqlen_q=max(lens),
+                                  max_seqlen_k=max(lens), softmax_scale=D**-0.5, causal=True)
+    assert torch.equal(out2, out)
+    with pytest.raises(RuntimeError, match="causal"):
+        triton_attention(q.to(DEV), k.to(DEV), v.to(DEV), None, cu.to(DEV), cu.to(DEV), max(lens), max(lens), False, D**-0.5, None)
+    with pytest.raises(RuntimeError, match="alibi_slopes"):
+        triton_attention(q.to(DEV), k.to(DEV), v.to(DEV), None, cu.to(DEV), cu.to(DEV), max(lens), max(lens), True, D**-0.5,
+                         torch.zeros(1, device=DEV))

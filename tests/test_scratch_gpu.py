@@ -1,6 +1,5 @@
-"""Split-K scratch lifetime under captured HIP graphs: a graph captured while a small scratch buffer
-was current must stay valid after a later eager call has made the binding switch to a larger one - the old buffer is
-retired, never freed. Also: the `Tensor! out` ops of torch_bindings write their operands in place."""
+"""Split-K scratch lifetime: per-call allocations, graph-private under capture,
+owned by a DeferredGemm until it is consumed. Also: the `Tensor! out` ops of torch_bindings write their operands in place."""
 import pytest
 import torch
 
@@ -18,47 +17,53 @@ def _quant(K, N, seed):
     return w_ref.float(), q.to(DEV), s.to(DEV)
 
 
-def test_graph_survives_scratch_regrowth(ops, monkeypatch):
-    monkeypatch.setattr(ops, "_SCRATCH_FLOOR", 1 << 20)
-    monkeypatch.setattr(ops, "_scratch", {})
-    monkeypatch.setattr(ops, "_retired", [])
+def test_scratch_is_per_call_and_graph_safe(ops):
+    """Round 3: split-K scratch is a per-call allocation (no module-level buffer pinned per stream). A captured graph's
+    scratch comes from the graph's private pool: replaying it after later eager calls of other sizes and after allocator
+    churn still gives the right result and writes into nobody else's memory; eager calls leave nothing allocated behind;
+    a DeferredGemm owns its slabs (a later GEMM on the same stream cannot clobber them)."""
+    assert not hasattr(ops, "_scratch") and not hasattr(ops, "_retired")
     e = torch.empty(0, dtype=torch.int32, device=DEV)
-    # decode-sized GEMM with cross-workgroup K splits (partials go through the scratch buffer)
-    K1, N1, M1 = 4096, 512, 16
+    K1, N1, M1 = 4096, 512, 16   # decode-sized GEMM with cross-workgroup K splits (partials go through the scratch)
     w1, q1, s1 = _quant(K1, N1, 1)
     a1 = torch.randn(M1, K1, dtype=torch.float16, device=DEV)
     ws1 = torch.zeros(N1 // 64 * 16, dtype=torch.int32, device=DEV)
     ref1 = a1.float().cpu() @ w1
+    assert ops._lib.lib().nmx_marlin_gemm_scratch_bytes(M1, N1, K1) > 0, "pick a shape that splits K"
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        ops.gptq_marlin_gemm(a1, q1, s1, e, e, ws1, 4, M1, N1, K1, True)  # allocates this stream's scratch (eager)
+        out = ops.gptq_marlin_gemm(a1, q1, s1, e, e, ws1, 4, M1, N1, K1, True)
         stream.synchronize()
-        small = [b for b in ops._scratch.values()]
-        assert small and max(b.numel() for b in small) == 1 << 20
+        assert compute_max_diff(out.cpu(), ref1) < 1e-3
+        del out
+        base = torch.cuda.memory_allocated()
+        for _ in range(3):
+            ops.gptq_marlin_gemm(a1, q1, s1, e, e, ws1, 4, M1, N1, K1, True)
+        stream.synchronize()
+        assert torch.cuda.memory_allocated() == base  # nothing pinned behind the calls
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream):
             out1 = ops.gptq_marlin_gemm(a1, q1, s1, e, e, ws1, 4, M1, N1, K1, True)
         g.replay()
         stream.synchronize()
         assert compute_max_diff(out1.cpu(), ref1) < 1e-3
-        # a bigger problem on the same stream: needs more than the 1 MiB buffer -> regrowth
+        # a bigger problem on the same stream, then allocator churn: the graph's slabs must be untouched by either
         K2, N2, M2 = 4096, 2048, 64
         w2, q2, s2 = _quant(K2, N2, 2)
         a2 = torch.randn(M2, K2, dtype=torch.float16, device=DEV)
         ws2 = torch.zeros(N2 // 64 * 16, dtype=torch.int32, device=DEV)
-        need = ops._lib.lib().nmx_marlin_gemm_scratch_bytes(M2, N2, K2)
-        assert need > (1 << 20), "pick a shape whose split-K partials exceed the test floor"
-        out2 = ops.gptq_marlin_gemm(a2, q2, s2, e, e, ws2, 4, M2, N2, K2, True)
+        d1 = ops.gptq_marlin_gemm_deferred(a1, q1, s1, e, e, ws1, 4, M1, N1, K1, True)   # slabs pending ...
+        out2 = ops.gptq_marlin_gemm(a2, q2, s2, e, e, ws2, 4, M2, N2, K2, True)           # ... while another GEMM runs
         stream.synchronize()
         assert compute_max_diff(out2.cpu(), a2.float().cpu() @ w2) < 1e-3
-        assert len(ops._retired) == 1 and ops._retired[0].numel() == 1 << 20  # the graph's buffer is still alive
-        # churn the allocator: anything that would have landed in a freed scratch block gets overwritten
+        assert d1.splits > 1 and compute_max_diff(d1.materialize().cpu(), ref1) < 1e-3
         junk = [torch.full((1 << 18,), 7.0, device=DEV) for _ in range(8)]
         out1.zero_()
         g.replay()
         stream.synchronize()
         assert compute_max_diff(out1.cpu(), ref1) < 1e-3
         assert all(bool((j == 7.0).all()) for j in junk)  # and the replay wrote into nobody else's memory
+    ops.release_scratch()
 
 
 def test_out_operands_written_in_place(ops):
