@@ -215,6 +215,21 @@ class Llama3Decode:
             self.max_logits = torch.empty(batch, nh, self.P, dtype=torch.float32, device=device)
         self.next_tokens = torch.zeros(batch, dtype=torch.long, device=device)
 
+    def gemm_as_in_step(self, x, w, name):
+        """The GEMM launch the captured step issues for this layer: with fused consumers (the default) the deferred form - the
+        GEMM kernel alone, its K-split slabs are summed by the consumer op -, otherwise the plain op (GEMM + reduce launch).
+        kernel_breakdown() times this, so `roofline.avg_launch_us` is the duration of the kernel the roofline is about."""
+        K, N = self.shapes[name]
+        ops = self.ops
+        if getattr(self, "fuse", False):
+            if self.variant == "int4":
+                return ops.gptq_marlin_gemm_deferred(x, w[0], w[1], self.empty, self.empty, self.workspace, 4, x.shape[0], N, K, True)
+            if self.variant == "sparse24":
+                return ops.gptq_marlin_24_gemm_deferred(x, w[0], w[1], w[2], self.workspace, 4, x.shape[0], N, K)
+            if self.variant.startswith("awq70b") and self.awq_marlin:
+                return ops.awq_marlin_gemm_deferred(x, w[0], w[1], w[2], x.shape[0], N, K)
+        return self.gemm(x, w, name)
+
     def gemm(self, x, w, name):
         K, N = self.shapes[name]
         ops = self.ops
@@ -418,7 +433,7 @@ def kernel_breakdown(model, reps=3):
 
         def run(name=name, x=x):
             for lw in model.layers:
-                model.gemm(x, lw[name], name)
+                model.gemm_as_in_step(x, lw[name], name)
 
         run()
         ms = time_events(run, reps) / nl
@@ -658,7 +673,7 @@ def main():
         # int4: the class is named after the kernel that serves most of its launches at this batch (rows > 64: the wide /
         # ring kernels of marlin_wide.hip, else the row-block kernel); every kernel of the class is listed for the PMC sums
         int4_names = ("marlin_wide_kernel", "marlin_gemm_kernel") if args.batch > 64 else ("marlin_gemm_kernel", "marlin_wide_kernel")
-        gemm_kernels = {"int4": int4_names + ("marlin_ring_kernel", "marlin_decode_kernel", "splitk_reduce_kernel"),
+        gemm_kernels = {"int4": int4_names + ("marlin_dma_kernel", "marlin_decode_kernel"),
                         "sparse24": ("marlin_gemm_kernel", "splitk_reduce_kernel"),
                         "fp8": ("scaled_mm_kernel", ),
                         "gptq-exllama": ("gptq_gemm_kernel", "splitk_reduce_kernel"),

@@ -165,6 +165,23 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
   const int s_voff = (nl + 2 * (lane & 31)) * 2;
   const int gs_shift = SCALED ? (31 - __builtin_clz((unsigned)max(p.group_size / 64, 1))) : 0;  // stages per group: a power of two
   const int st_last = min(st_begin + max(nst - 1, 0), total_stages - 1);
+  // Every column tile reads the SAME activation rows; workgroups that walk K in the same order ask for the same few L2 lines at
+  // the same time. Each workgroup therefore starts its K walk at its own offset and wraps around (the same products, summed in a
+  // rotated order) - as marlin_wide_kernel does, with the offset a function of the PLAIN column tile and periodic over the two
+  // halves of N, so that a fused gate | up tile walks K in the order both of its halves have in the plain launch (the fused op
+  // stays bit-identical to GEMM + silu_and_mul). Row blocks of a column tile share the offset (the second one hits L2).
+#ifndef NMX_DMA_ROT
+#define NMX_DMA_ROT 1
+#endif
+  const int n_tiles_r = (N + 64 * kWN - 1) / (64 * kWN);
+  const int period_r = (N % (128 * kWN) == 0) ? n_tiles_r / 2 : n_tiles_r;
+  const int tile_plain = fuse_act ? tile_x >> 1 : tile_x;
+  const int rot = (NMX_DMA_ROT && nst > 1) ? (int)(((int64_t)(tile_plain % max(period_r, 1)) * nst) / max(period_r, 1)) % nst : 0;
+  auto stage_abs = [&](int rel) {  // absolute stage of walk position rel (past the range: some valid stage, never consumed)
+    int r = min(rel, max(nst - 1, 0)) + rot;
+    r = r >= nst ? r - nst : r;
+    return min(st_begin + max(r, 0), total_stages - 1);
+  };
   // DMA instruction J (0, 1: packed words; 2 .. 5: activations; 6: scales) of a batch: weights + scales of absolute stage sw
   // into ring slot SW, activations of stage sa into slot SA (positions past the range: the last stage again, never consumed)
   auto issue_one = [&](auto j_c, auto sw_c, auto sa_c, int sw, int sa) {
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
 #endif
   };
   auto issue = [&](auto sw_c, auto sa_c, int rel_w, int rel_a) {  // a whole batch at once (prologue)
-    const int sw = min(st_begin + rel_w, st_last), sa = min(st_begin + rel_a, st_last);
+    const int sw = stage_abs(rel_w), sa = stage_abs(rel_a);
     issue_one(std::integral_constant<int, 0>{}, sw_c, sa_c, sw, sa);
     issue_one(std::integral_constant<int, 1>{}, sw_c, sa_c, sw, sa);
     issue_one(std::integral_constant<int, 2>{}, sw_c, sa_c, sw, sa);
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
     // waves stalled on the vector-memory issue together right after the barrier and the matrix pipes idled meanwhile
     // (timing ablation: 19 of gate_up's 66 us at M = 256). One instruction goes out behind every second MFMA row, the two
     // K-groups (= the two waves of a SIMD) on alternate rows.
-    const int sw_n = (NMX_DABLATE & 64) ? st_begin : min(st_begin + it + 3, st_last), sa_n = (NMX_DABLATE & 64) ? st_begin : min(st_begin + it + 2, st_last);
+    const int sw_n = (NMX_DABLATE & 64) ? st_begin : stage_abs(it + 3), sa_n = (NMX_DABLATE & 64) ? st_begin : stage_abs(it + 2);
     auto dma_at = [&](auto r_c) {  // R = 0 .. 15: MFMA row of the stage
       constexpr int R = decltype(r_c)::value;
       constexpr bool skip = ((NMX_DABLATE & 1024) != 0 && (R >> 1) < 2) || ((NMX_DABLATE & 2048) != 0 && (R >> 1) >= 2 && (R >> 1) < 6) ||

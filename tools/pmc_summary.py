@@ -22,7 +22,7 @@ def rows(d, suffix):
 
 def short(name):
     n = name
-    for key in ("marlin_gemm_kernel", "marlin_wide_kernel", "marlin_decode_kernel", "marlin_large_kernel", "paged_attention_kernel", "paged_attention_fp8w_kernel", "paged_attention_v2_reduce_kernel", "splitk_reduce_kernel",
+    for key in ("marlin_dma_kernel", "marlin_pc_kernel", "marlin_gemm_kernel", "marlin_wide_kernel", "marlin_decode_kernel", "marlin_large_kernel", "paged_attention_kernel", "paged_attention_fp8w_kernel", "paged_attention_v2_reduce_kernel", "splitk_reduce_kernel",
                 "rms_norm_splitk_kernel", "silu_and_mul_splitk_kernel", "rope_cache_kernel", "prefill_attention_shared_kernel", "prefill_attention_kernel",
                 "rms_norm_vec_kernel", "rotary_kernel", "act_and_mul_kernel", "reshape_and_cache_vec_kernel",
                 "reshape_and_cache_kernel", "Cijk", "gptq_gemm_kernel", "awq_gemm_kernel", "scaled_mm_tile_kernel", "scaled_mm_lds_kernel",
