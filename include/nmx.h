@@ -374,6 +374,13 @@ int nmx_moe_scaled_mm(void* out, const void* a, const void* w, const float* a_sc
                       const int32_t* num_tokens_post_padded, int num_valid, int a_rows, int a_row_div, int n, int k,
                       int num_experts, int block_rows, int max_blocks, int out_dtype, nmx_stream_t stream);
 
+/* Unquantised form of nmx_moe_scaled_mm (round 3): a [rows, k] and w [E, n, k] in `dtype` (fp16 / bf16), k a multiple of 64;
+ * out[id, :] = cast((a[id / a_row_div] . w[expert_of(id)]) * [topk_weights[id]]) - the reference's Triton fused_moe_kernel with
+ * use_fp8 = False (vllm/model_executor/layers/fused_moe/fused_moe.py:20-292). Nothing is read on the host: capturable. */
+int nmx_moe_mm(void* out, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
+               const int32_t* expert_ids, const int32_t* num_tokens_post_padded, int num_valid, int a_rows, int a_row_div, int n, int k,
+               int num_experts, int block_rows, int max_blocks, int dtype, nmx_stream_t stream);
+
 /*
  * All-reduce over the xGMI mesh for decode-sized messages. Replaces the `_C_custom_ar` ops of the reference
  * (csrc/custom_all_reduce.cu: meta_size, init_custom_ar, register_buffer, should_custom_ar, all_reduce_reg, dispose; kernels

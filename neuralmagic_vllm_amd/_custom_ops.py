@@ -1092,6 +1092,30 @@ def moe_scaled_mm(out: torch.Tensor, a: torch.Tensor, w: torch.Tensor, a_scale: 
         c_int(w.shape[0]), c_int(block_rows), c_int(expert_ids.numel()), c_int(_dt(out)), _stream(a)))
 
 
+def moe_mm(out: torch.Tensor, a: torch.Tensor, w: torch.Tensor, topk_weights: Optional[torch.Tensor], sorted_token_ids: torch.Tensor,
+           expert_ids: torch.Tensor, num_tokens_post_padded: torch.Tensor, a_row_div: int, block_rows: int) -> None:
+    """Grouped fp16 / bf16 GEMM over the expert-sorted (token, k) pairs (the reference's Triton fused_moe_kernel with
+    use_fp8 = False, fused_moe.py:20-292): out[id] = (a[id // a_row_div] @ w[expert].T) * [topk_weights[id]].
+    a [rows, K], w [E, N, K], out [num_valid, N], all the same dtype. No host reads: graph-capturable."""
+    _dev(a)
+    if a.dtype not in (torch.float16, torch.bfloat16) or w.dtype != a.dtype or out.dtype != a.dtype or not (a.is_contiguous() and w.is_contiguous()):
+        raise RuntimeError("moe_mm: a, w and out must be contiguous float16 / bfloat16 tensors of one dtype")
+    if w.dim() != 3 or a.dim() != 2 or w.shape[2] != a.shape[1] or out.shape[1] != w.shape[1] or not out.is_contiguous():
+        raise RuntimeError("moe_mm: shapes a [rows, K], w [E, N, K], out [num_valid, N]")
+    for t in (sorted_token_ids, expert_ids, num_tokens_post_padded):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("moe_mm: index tensors must be contiguous int32")
+    tw = None
+    if topk_weights is not None:
+        tw = topk_weights.reshape(-1)
+        if tw.dtype != torch.float32 or not tw.is_contiguous() or tw.numel() != out.shape[0]:
+            raise RuntimeError("moe_mm: topk_weights must be float32 with one entry per output row")
+    _lib.check(_lib.lib().nmx_moe_mm(
+        _p(out), _p(a), _p(w), _p(tw), _p(sorted_token_ids), _p(expert_ids), _p(num_tokens_post_padded), c_int(out.shape[0]),
+        c_int(a.shape[0]), c_int(a_row_div), c_int(w.shape[1]), c_int(w.shape[2]), c_int(w.shape[0]), c_int(block_rows),
+        c_int(expert_ids.numel()), c_int(_dt(out)), _stream(a)))
+
+
 def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, token_expert_indicies: torch.Tensor,
                  gating_output: torch.Tensor) -> None:
     _dev(gating_output)

@@ -116,8 +116,12 @@ struct MoeMmParams {
   int N, K, num_valid, a_row_div, a_rows;
 };
 
-template <typename out_t, int MT>
+// HALF = true (round 3): the unquantised form of the same kernel - a and w hold out_t (fp16 / bf16) elements, a 128-byte stage is
+// 64 k, the MFMA is v_mfma_f32_16x16x32_{f16,bf16} on the 16-byte chunks as loaded (natural k order on both operands), and the
+// epilogue is the routing weight alone (fused_moe.py:186-195 with use_fp8 = False). p.K stays the row length in ELEMENTS.
+template <typename out_t, int MT, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void moe_scaled_mm_kernel(const MoeMmParams p) {
+  constexpr int ES = HALF ? 2 : 1;  // bytes per element of a and w
   constexpr int NT = 4;
   constexpr int BROWS = 64, AROWS = 16 * MT;
   constexpr int BI = BROWS / 8, AI = AROWS / 8;
@@ -134,25 +138,25 @@ __global__ __launch_bounds__(256, 2) void moe_scaled_mm_kernel(const MoeMmParams
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int stages = p.K / 128;
+  const int stages = p.K * ES / 128;
   const int pw = (stages + 3) / 4;
   const int ws = min(wave * pw, stages), we = min(ws + pw, stages);
   const int len = we - ws;
 
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(p.w + (int64_t)expert * p.N * p.K), 0, (int)((int64_t)p.N * p.K), 0x00020000);
+      const_cast<uint8_t*>(p.w + (int64_t)expert * p.N * p.K * ES), 0, (int)((int64_t)p.N * p.K * ES), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.a), 0, (int)((int64_t)p.a_rows * p.K), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.a), 0, (int)((int64_t)p.a_rows * p.K * ES), 0x00020000);
   int b_voff[BI], a_voff[AI];
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
     const int n = n0 + 8 * j + lr;
-    b_voff[j] = n < p.N ? (int)(n * p.K + 16 * lc) : (int)0xfffffff0u;  // rows past the matrix read as zeros
+    b_voff[j] = n < p.N ? (int)(n * p.K * ES + 16 * lc) : (int)0xfffffff0u;  // rows past the matrix read as zeros
   }
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int id = p.sorted_token_ids[blk * AROWS + 8 * j + lr];
-    a_voff[j] = id < p.num_valid ? (int)((id / p.a_row_div) * p.K + 16 * lc) : (int)0xfffffff0u;  // padding slot
+    a_voff[j] = id < p.num_valid ? (int)((id / p.a_row_div) * p.K * ES + 16 * lc) : (int)0xfffffff0u;  // padding slot
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* img = smem + wave * ((BROWS + AROWS) * 128);
@@ -183,6 +187,13 @@ __global__ __launch_bounds__(256, 2) void moe_scaled_mm_kernel(const MoeMmParams
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          if constexpr (HALF) {
+            if constexpr (__is_same(out_t, f16))
+              acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[t]), __builtin_bit_cast(f16x8, af[mt]), acc[mt][t], 0, 0, 0);
+            else
+              acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[t]), __builtin_bit_cast(bf16x8, af[mt]), acc[mt][t], 0, 0, 0);
+            continue;
+          }
           const long b0 = (long)(((uint64_t)bf[t][1] << 32) | bf[t][0]), b1 = (long)(((uint64_t)bf[t][3] << 32) | bf[t][2]);
           const long a0 = (long)(((uint64_t)af[mt][1] << 32) | af[mt][0]), a1 = (long)(((uint64_t)af[mt][3] << 32) | af[mt][2]);
           acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b0, a0, acc[mt][t], 0, 0, 0);
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void moe_scaled_mm_kernel(const MoeMmParams
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[mt][t] += red[((w * MT + mt) * NT + t) * 64 + lane];
-  const float sa = p.a_scale[0], sb = p.w_scale[expert];
+  const float sa = HALF ? 1.0f : p.a_scale[0], sb = HALF ? 1.0f : p.w_scale[expert];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int id = p.sorted_token_ids[blk * AROWS + 16 * mt + li];
@@ -232,20 +243,20 @@ __global__ __launch_bounds__(256, 2) void moe_scaled_mm_kernel(const MoeMmParams
       for (int r = 0; r < 4; ++r) {
         float v = acc[mt][t][r];
         if (p.topk_weights != nullptr) v = v * rw;  // fused_moe.py:186-190: routed weight first, then the fp8 scales
-        o.h[r] = Scalar<out_t>::from_f32(v * sa * sb);  // :192-193
+        o.h[r] = Scalar<out_t>::from_f32(HALF ? v : v * sa * sb);  // :192-195
       }
       *reinterpret_cast<u32x2*>(reinterpret_cast<out_t*>(p.out) + (int64_t)id * p.N + n) = o.u;
     }
   }
 }
 
-template <typename out_t>
+template <typename out_t, bool HALF = false>
 int launch_moe_mm(const MoeMmParams& p, int block_rows, int max_blocks, hipStream_t stream) {
   dim3 grid(ceil_div(p.N, 64), max_blocks, 1);
 #define NMX_MOE(MT_)                                                                                   \
   {                                                                                                    \
     const size_t smem = std::max((size_t)4 * (64 + 16 * MT_) * 128, (size_t)3 * MT_ * 4 * 64 * 16);     \
-    moe_scaled_mm_kernel<out_t, MT_><<<grid, 256, smem, stream>>>(p);                                  \
+    moe_scaled_mm_kernel<out_t, MT_, HALF><<<grid, 256, smem, stream>>>(p);                            \
   }
   if (block_rows == 16) NMX_MOE(1) else if (block_rows == 32) NMX_MOE(2) else NMX_MOE(4)
 #undef NMX_MOE
@@ -297,4 +308,25 @@ extern "C" int nmx_moe_scaled_mm(void* out, const void* a, const void* w, const 
   p.N = n; p.K = k; p.num_valid = num_valid; p.a_row_div = a_row_div; p.a_rows = a_rows;
   if (out_dtype == NMX_F16) return launch_moe_mm<f16>(p, block_rows, max_blocks, (hipStream_t)stream);
   return launch_moe_mm<bf16>(p, block_rows, max_blocks, (hipStream_t)stream);
+}
+
+// The unquantised grouped GEMM of fused_moe (fused_moe.py:20-222 with use_fp8 = False; round 3): a [rows, K] and w [E, N, K] in the
+// output dtype (fp16 / bf16), out[id, :] = cast((sum_k a[id / a_row_div, k] * w[e, :, k]) * [topk_weights[id]]). Same blocks,
+// gather / scatter and graph-capturability as nmx_moe_scaled_mm.
+extern "C" int nmx_moe_mm(void* out, const void* a, const void* w, const float* topk_weights, const int32_t* sorted_token_ids,
+                          const int32_t* expert_ids, const int32_t* num_tokens_post_padded, int num_valid, int a_rows, int a_row_div,
+                          int n, int k, int num_experts, int block_rows, int max_blocks, int dtype, nmx_stream_t stream) {
+  NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "moe_mm: float16 / bfloat16 only");
+  NMX_CHECK(block_rows == 16 || block_rows == 32 || block_rows == 64, NMX_ERR_INVALID_ARG, "moe_mm: block size 16, 32 or 64, got %d", block_rows);
+  NMX_CHECK(k % 64 == 0 && n % 4 == 0, NMX_ERR_UNSUPPORTED, "moe_mm: K must be a multiple of 64 and N of 4 (K = %d, N = %d)", k, n);
+  NMX_CHECK(a_row_div >= 1 && num_experts >= 1 && (int64_t)n * k * 2 < (1ll << 31) && (int64_t)a_rows * k * 2 < (1ll << 31), NMX_ERR_INVALID_ARG,
+            "moe_mm: bad shape");
+  NMX_CHECK(((uintptr_t)a | (uintptr_t)w) % 16 == 0 && (uintptr_t)out % 8 == 0, NMX_ERR_INVALID_ARG, "moe_mm: operands must be 16-byte aligned");
+  if (num_valid == 0 || max_blocks == 0) return NMX_OK;
+  MoeMmParams p;
+  p.a = (const uint8_t*)a; p.w = (const uint8_t*)w; p.out = out; p.a_scale = nullptr; p.w_scale = nullptr; p.topk_weights = topk_weights;
+  p.sorted_token_ids = sorted_token_ids; p.expert_ids = expert_ids; p.num_tokens_post_padded = num_tokens_post_padded;
+  p.N = n; p.K = k; p.num_valid = num_valid; p.a_row_div = a_row_div; p.a_rows = a_rows;
+  if (dtype == NMX_F16) return launch_moe_mm<f16, true>(p, block_rows, max_blocks, (hipStream_t)stream);
+  return launch_moe_mm<bf16, true>(p, block_rows, max_blocks, (hipStream_t)stream);
 }

@@ -3,8 +3,9 @@ fp8 MoE method calls (fused_topk :335-368, fused_experts :402-511, fused_moe :51
 grouped-GEMM kernel over tokens sorted by expert; here routing is native HIP (topk_softmax, moe_align_block_size) and
 the fp8 path runs the two expert GEMMs as ONE grouped launch each over the sorted blocks (`moe_scaled_mm`: rows gathered
 through sorted_token_ids, results scattered to their pair id; nothing is read back on the host, so the layer is
-graph-capturable like the reference's). The unquantised path (not a target of this build) multiplies per expert with
-torch.matmul and reads the per-expert row counts on the host. Arithmetic follows the reference: one per-tensor activation scale for the
+graph-capturable like the reference's). Round 3: the unquantised fp16 / bf16 path runs the same grouped kernel (`moe_mm`);
+only shapes it does not take (K or N not multiples of 64, fp32 activations) fall back to a per-expert torch.matmul loop that
+reads the per-expert row counts on the host. Arithmetic follows the reference: one per-tensor activation scale for the
 whole batch (static, or dynamic = max over all tokens), per-expert weight scales, fp32 accumulation, routing weights
 applied to the expert outputs before the sum over k."""
 from typing import Optional, Tuple
@@ -49,6 +50,8 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     numel = m * topk
     if use_fp8 and dt in (torch.float16, torch.bfloat16) and k % 128 == 0 and (n2 // 2) % 128 == 0:
         return _fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, w1_scale, w2_scale, a1_scale, a2_scale)
+    if not use_fp8 and dt in (torch.float16, torch.bfloat16) and w1.dtype == dt and w2.dtype == dt and k % 64 == 0 and (n2 // 2) % 64 == 0:
+        return _fused_experts_half(hidden_states, w1, w2, topk_weights, topk_ids, inplace)
     # tokens sorted by expert (block size 1: no padding needed for per-expert slices)
     sorted_ids = torch.empty(numel, dtype=torch.int32, device=dev)
     expert_of_block = torch.empty(numel, dtype=torch.int32, device=dev)
@@ -83,6 +86,32 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     acc = torch.zeros(m, w2.shape[1], dtype=torch.float32, device=dev)
     acc.index_add_(0, src_tok, out_rows.float() * wts[:, None])
     out.copy_(acc.to(dt))
+    return out
+
+
+def _fused_experts_half(hidden_states, w1, w2, topk_weights, topk_ids, inplace):
+    """fused_experts without quantisation (fused_moe.py:402-511, use_fp8 = False) on the grouped MFMA kernel (round 3; rounds 1-2
+    looped over the experts with torch.matmul and read the expert histogram on the host): align -> grouped GEMM (gate | up) ->
+    silu_and_mul -> grouped GEMM with the routing weight -> sum over k. Every step is a device launch: graph-capturable."""
+    m, k = hidden_states.shape
+    e, n2, _ = w1.shape
+    topk = topk_ids.shape[1]
+    dev, dt = hidden_states.device, hidden_states.dtype
+    numel = m * topk
+    block = 16 if numel <= 16 * e else 64  # get_default_config's BLOCK_SIZE_M (:308-332)
+    max_sorted = numel + e * (block - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=dev)
+    expert_ids = torch.empty((max_sorted + block - 1) // block, dtype=torch.int32, device=dev)
+    post_pad = torch.empty(1, dtype=torch.int32, device=dev)
+    ops.moe_align_block_size(topk_ids.contiguous(), e, block, sorted_ids, expert_ids, post_pad)
+    gate_up = torch.empty(numel, n2, dtype=dt, device=dev)
+    ops.moe_mm(gate_up, hidden_states, w1, None, sorted_ids, expert_ids, post_pad, topk, block)
+    inter = torch.empty(numel, n2 // 2, dtype=dt, device=dev)
+    ops.silu_and_mul(inter, gate_up)
+    out_rows = torch.empty(numel, w2.shape[1], dtype=dt, device=dev)
+    ops.moe_mm(out_rows, inter, w2, topk_weights.float().contiguous(), sorted_ids, expert_ids, post_pad, 1, block)
+    out = hidden_states if inplace else torch.empty_like(hidden_states)
+    torch.sum(out_rows.view(m, topk, w2.shape[1]), dim=1, out=out)  # moe_sum (:505-510)
     return out
 
 

@@ -129,6 +129,29 @@ def test_awq_method(m):
     assert compute_max_diff(out.cpu(), x.float() @ w_ref.float()) < 2e-3
 
 
+@pytest.mark.parametrize("m", [4, 300])
+def test_awq_method_repacked_releases_checkpoint_layout(m):
+    """process_weights_after_loading repacks onto the Marlin kernel and drops qweight / qzeros / scales (both layouts
+    resident doubled the AWQ weight memory); apply() keeps working from the repacked tensors alone."""
+    from neuralmagic_vllm_amd.layers.quantization.awq import AWQConfig
+    seed_all(2)
+    K, N, G = 512, 256, 128
+    cfg = AWQConfig.from_config({"w_bit": 4, "q_group_size": G, "zero_point": True})
+    method = cfg.get_quant_method(None)
+    layer = Layer()
+    method.create_weights(layer, K, [N], K, N, torch.float16)
+    w_ref, qweight, qzeros, scales = packing.awq_quantize(torch.randn(K, N), G)
+    load(layer, qweight=qweight, qzeros=qzeros, scales=scales)
+    layer.to(DEV)
+    method.process_weights_after_loading(layer)
+    assert layer.marlin_q is not None and layer.qweight.numel() == 0 and layer.qzeros.numel() == 0 and layer.scales.numel() == 0
+    x = torch.randn(m, K, dtype=torch.float16)
+    out = method.apply(layer, x.to(DEV))
+    assert out.shape == (m, N) and compute_max_diff(out.cpu(), x.float() @ w_ref.float()) < 2e-3
+    with pytest.raises(RuntimeError, match="NMX_AWQ_KEEP_CHECKPOINT_LAYOUT"):
+        method.apply(layer, x.to(DEV).bfloat16())
+
+
 @pytest.mark.parametrize("desc_act", [False, True])
 def test_gptq_method(desc_act):
     from neuralmagic_vllm_amd.layers.quantization.gptq import ExllamaState, GPTQConfig

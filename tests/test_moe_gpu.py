@@ -182,3 +182,61 @@ def test_fused_moe_fp8_is_graph_capturable(ops):
         g.replay()
         side.synchronize()
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("m,e,topk,block", [(1, 8, 2, 16), (33, 8, 2, 16), (222, 8, 2, 64), (40, 64, 6, 32)])
+@pytest.mark.parametrize("n,k", [(256, 128), (1000, 448)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_moe_mm_unquantised(ops, m, e, topk, block, n, k, dtype):
+    """Round 3: the unquantised grouped GEMM (the reference's Triton fused_moe_kernel with use_fp8 = False, fused_moe.py:20-292)
+    against a per-pair fp32 torch evaluation: gather through sorted_token_ids, optional routing weight, scatter to the pair id;
+    padding slots and blocks past num_tokens_post_padded do nothing (the canary value survives nowhere a row is valid)."""
+    seed_all(m + n)
+    numel = m * topk
+    ids = torch.stack([torch.randperm(e)[:topk] for _ in range(m)]).int().to(DEV)
+    a = (torch.randn(m, k, device=DEV) / 4).to(dtype)
+    w = (torch.randn(e, n, k, device=DEV) / 4).to(dtype)
+    tw = torch.rand(m, topk, device=DEV)
+    max_sorted = numel + e * (block - 1)
+    sorted_ids = torch.empty(max_sorted, dtype=torch.int32, device=DEV)
+    expert_ids = torch.zeros((max_sorted + block - 1) // block, dtype=torch.int32, device=DEV)
+    post = torch.empty(1, dtype=torch.int32, device=DEV)
+    ops.moe_align_block_size(ids, e, block, sorted_ids, expert_ids, post)
+    for use_tw in (False, True):
+        out = torch.full((numel, n), 7.0, dtype=dtype, device=DEV)
+        ops.moe_mm(out, a, w, tw if use_tw else None, sorted_ids, expert_ids, post, topk, block)
+        flat = ids.flatten().long()
+        rows = torch.arange(numel, device=DEV) // topk
+        ref = torch.einsum("rk,rnk->rn", a.float()[rows], w.float()[flat])
+        if use_tw:
+            ref = ref * tw.flatten()[:, None]
+        tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1.6e-2, atol=1.6e-2)
+        torch.testing.assert_close(out.float(), ref.to(dtype).float(), **tol)
+
+
+def test_fused_moe_unquantised_is_graph_capturable(ops):
+    """The fp16 MoE layer is device launches only since round 3 (no host read of the expert histogram): capture + replay."""
+    from neuralmagic_vllm_amd.layers.fused_moe import fused_experts, fused_topk
+    seed_all(4)
+    e, n, k, m, topk = 8, 256, 512, 24, 2
+    w1 = (torch.randn(e, 2 * n, k, device=DEV) / 10).half()
+    w2 = (torch.randn(e, k, n, device=DEV) / 10).half()
+    x = torch.randn(m, k, dtype=torch.float16, device=DEV) / 10
+    logits = torch.randn(m, e, device=DEV)
+
+    def run():
+        tw, ids = fused_topk(x, logits, topk, True)
+        return fused_experts(x, w1, w2, tw, ids)
+
+    eager = run().clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = run()
+        out.zero_()
+        g.replay()
+        side.synchronize()
+    assert torch.equal(out, eager)
