@@ -457,8 +457,9 @@ __global__ __launch_bounds__(256, 2) void scaled_mm_lds_kernel(const MmParams p)
 // reads the fragments of its 64 x 64 sub-tile: 16 ds_read_b128 per 64 (fp8) / 32 (int8) MFMAs. LDS double-buffered, the
 // next stage's global loads in flight during the MFMAs, one workgroup barrier per stage.
 // grid (ceil(N / (64 WN)), k_splits, ceil(M / (64 WM))), block 64 WM WN; LDS NBUF x 64 (WM + WN) x 128 B.
-template <typename out_t, bool FP8, int WM, int WN, int NBUF>
+template <typename out_t, bool FP8, int WM, int WN, int NBUF, bool PIPE = false>
 __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmParams p) {
+  static_assert(!PIPE || (FP8 && NBUF == 3), "the fragment-pipelined form is the fp8 three-buffer DMA loop");
   constexpr int NWAVE = WM * WN;
   constexpr int AROWS = 64 * WM, BROWS = 64 * WN;
   constexpr int PIECES = (AROWS + BROWS) / 8;     // 8-row x 128-byte pieces per stage
@@ -598,6 +599,9 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
     const int c = lc ^ f;
     if (q < AROWS / 8) gvoff[j] = (int)(min(m0 + r, p.M - 1) * p.lda + 16 * c);   // rows past the matrix: a valid row again,
     else gvoff[j] = (int)(min(n0 + r - AROWS, p.N - 1) * p.ldb + 16 * c);         // its outputs are never stored
+    // timing experiment (wrong products): the weight tile of a stage as ONE contiguous BROWS x 128-byte block
+    if constexpr ((NMX_TABLATE & 8) != 0)
+      if (q >= AROWS / 8) gvoff[j] = (int)(n0 * p.ldb + (r - AROWS) * 128 + 16 * c);
   }
   auto dma = [&](int s, char* img) {
     int r = min(s - sb, nst - 1) + rot;
@@ -618,7 +622,76 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
     u32x4 ra[PW], rb[PW];
     // (with two buffers - one stage of lookahead, vmcnt(0) at every barrier - the DMA form measured 10-20 % SLOWER than the
     // two-register-set pipeline below, which keeps two stages of loads in flight: three buffers only)
-    if constexpr (FP8 && NBUF == 3) {
+    if constexpr (PIPE) {
+      // Round 3: fragment-pipelined form. In the loop below (round 2) a stage is [16 fragment reads -> wait -> 16 MFMAs ->
+      // barrier] and the eight waves of the workgroup run it in step, so the LDS array and the matrix pipes take turns
+      // (rocprofv3: 2,830 cycles per stage against 1,024 of MFMA issue for the two waves of a SIMD). Here the fragments of
+      // stage s + 1 are read into a second register set BETWEEN the MFMAs of stage s (one ds_read_b128 per MFMA), and the
+      // stage's DMA instructions are spread over the same MFMAs, so every wave is in its MFMA stream all the time. Stage s
+      // lives in registers while it is multiplied, hence the three buffers hold stages s + 1 (being read), s + 2 (landing,
+      // awaited at the end of s) and s + 3 (issued during s into the buffer stage s left at the previous barrier).
+      u32x4 fr[2][16];  // [set][2 o + half]: o = 0..3 weight column tiles, 4..7 activation row tiles
+      const int iao = (64 * wm) * 128, ibo = (AROWS + 64 * wn) * 128;
+      auto rd = [&](const char* img, int o, int h) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(img + (o < 4 ? ibo : iao) + slot(16 * (o & 3) + li, 2 * g + h));
+      };
+      auto stage_soff = [&](int s) {
+        int r = min(s - sb, nst - 1) + rot;
+        r = r >= nst ? r - nst : r;
+        return (sb + r) * 128;
+      };
+      auto dma_one = [&](int j, int soff, char* img) {
+        if constexpr ((NMX_TABLATE & 1) != 0) return;            // timing experiments: no in-loop DMA at all,
+        if constexpr ((NMX_TABLATE & 2) != 0) if (!is_a[j]) return;  // activations only,
+        if constexpr ((NMX_TABLATE & 16) != 0) if (is_a[j]) return;  // weights only
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto* dst = (__attribute__((address_space(3))) void*)(img + (wave * PW + j) * 1024);
+        if (is_a[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, gvoff[j], soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst, 16, gvoff[j], (NMX_TABLATE & 8) != 0 ? soff * BROWS : soff, 0, 0);
+#endif
+      };
+      auto cat8 = [](const u32x4& lo, const u32x4& hi) {
+        return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      };
+      // stage s (fragments in set X) is multiplied while stage s + 1 is read from `inext` into set X ^ 1 and stage s + 3 is
+      // fetched into `idma` (the buffer stage s was read from)
+      auto body = [&](int s, const char* inext, char* idma, auto setc) {
+        constexpr int X = decltype(setc)::value, Y = X ^ 1;
+        const int soff = stage_soff(s + 3);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = i >> 2, mt = i & 3;
+          acc[mt][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(fr[X][2 * t], fr[X][2 * t + 1]),
+                                                                        cat8(fr[X][8 + 2 * mt], fr[X][9 + 2 * mt]), acc[mt][t], 0, 0,
+                                                                        0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          // next stage's fragments in the order its MFMAs need them: weight tile 0, the four row tiles, weight tiles 1..3
+          constexpr int order[16] = {0, 1, 8, 9, 10, 11, 12, 13, 14, 15, 2, 3, 4, 5, 6, 7};
+          fr[Y][order[i]] = rd(inext, order[i] >> 1, order[i] & 1);
+#pragma unroll
+          for (int j = 0; j < PW; ++j)
+            if (j * 16 / PW == i) dma_one(j, soff, idma);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // own reads of stage s + 1 done (its buffer takes stage s + 4 next), stage s + 2 landed (all but the newest DMAs)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW) : "memory");
+      };
+      dma(sb, smem);
+      dma(sb + 1, smem + IMG);
+      dma(sb + 2, smem + 2 * IMG);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PW) : "memory");  // stage 0 landed everywhere
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fr[0][i] = rd(smem, i >> 1, i & 1);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW) : "memory");  // stage 1 landed, buffer 0 released
+      int cur = 0;  // buffer stage s was read from
+      for (int s = sb; s < se; s += 2) {
+        const int n1 = cur + 1 == NBUF ? 0 : cur + 1, n2 = n1 + 1 == NBUF ? 0 : n1 + 1;
+        body(s, smem + n1 * IMG, smem + cur * IMG, std::integral_constant<int, 0>{});
+        if (s + 1 >= se) break;
+        body(s + 1, smem + n2 * IMG, smem + n1 * IMG, std::integral_constant<int, 1>{});
+        cur = n2;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped DMAs past the split: nothing may land after the exit
+    } else if constexpr (FP8 && NBUF == 3) {
       constexpr int LA = NBUF - 1;  // stages of DMA lookahead
       dma(sb, smem);
       if constexpr (LA == 2) dma(sb + 1, smem + IMG);
@@ -684,22 +757,32 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
 
 // tile shape and K splits of scaled_mm_tile_kernel: 128 x 256 tiles when they alone give >= 128 workgroups, else
 // 128 x 128 tiles with K splits until >= 192 workgroups exist (>= 8 stages per split)
-struct TileCfg { int wn, splits; };
-inline TileCfg mm_tile_cfg(int M, int N, int K) {
-  TileCfg c{4, 1};
+struct TileCfg { int wn, splits, pipe; };
+inline TileCfg mm_tile_cfg(int M, int N, int K, bool fp8) {
+  TileCfg c{4, 1, 1};
   const int rows = ceil_div(M, 128), stages = K / 128;
-  int force = 0;  // NMX_MM_TILE=2 / 4: force the 128-column / 256-column tile (sweeps)
-  if (const char* e = nmx_tune(NMX_TUNE_MM_TILE)) force = atoi(e);
-  // long K with few tiles (down: 14336 x 4096 at M = 256): the 256-column DMA tile with K splits (41.8 vs 44.4 us)
+  // NMX_MM_TILE="wn[,splits[,form]]" (sweeps): wn 2 / 4 = the 128- / 256-column tile, splits 0 = the rule's, form 0 = the
+  // round-2 loop (fp8, wn 4: DMA, fragments read per stage; wn 2: register-staged), 1 = the fragment-pipelined DMA loop
+  int force = 0, fsplits = 0;
+  if (const char* e = nmx_tune(NMX_TUNE_MM_TILE)) {
+    int f = 1;
+    const int got = sscanf(e, "%d,%d,%d", &force, &fsplits, &f);
+    if (got >= 3) c.pipe = f;
+  }
+  // long K with few tiles (down: 14336 x 4096): the 256-column DMA tile with K splits - int8 from M = 65, fp8 above M = 256
+  // (fp8, round 3: the fragment-pipelined 128-column tile is ahead up to there - M = 128: 24.8 vs 29.2 us, M = 256: 31.9 vs
+  // 35.2, M = 512: 50.2 vs 44.5; profiles/r03_fp8_tile_experiments.txt)
   const int tiles4 = rows * ceil_div(N, 256);
-  const bool long_k = K >= 8192 && tiles4 >= 16;
+  const bool long_k = K >= 8192 && tiles4 >= 16 && !(fp8 && c.pipe != 0 && rows <= 2);
   if (force != 2 && (force == 4 || long_k || tiles4 >= 128)) {
     while ((force == 4 || long_k) && tiles4 * c.splits < 192 && c.splits < 16 && stages / (c.splits * 2) >= 4) c.splits *= 2;
+    if (fsplits > 0) c.splits = fsplits;
     return c;
   }
   c.wn = 2;
   const int tiles = rows * ceil_div(N, 128);
   while (tiles * c.splits < 192 && c.splits < 16 && stages / (c.splits * 2) >= 8) c.splits *= 2;
+  if (fsplits > 0) c.splits = fsplits;
   return c;
 }
 inline bool mm_use_tile(int M, int N, int K) {
@@ -732,7 +815,7 @@ inline int mm_splits(int M, int N, int K) {
 
 template <typename out_t, bool FP8>
 int launch_mm_tile(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
-  const TileCfg c = mm_tile_cfg(p.M, p.N, p.K);
+  const TileCfg c = mm_tile_cfg(p.M, p.N, p.K, FP8);
   p.k_splits = c.splits;
   const int64_t per = (int64_t)p.M * p.N * 4;
   if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to what fits
@@ -741,15 +824,23 @@ int launch_mm_tile(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
   }
   p.partial = scratch;
   dim3 grid(ceil_div(p.N, 64 * c.wn), p.k_splits, ceil_div(p.M, 128));
-  const int smem = (c.wn == 4 ? 3 : 2) * 64 * (2 + c.wn) * 128;
-  if (c.wn == 4) {
-    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 4, 3>;
+  const bool pipe = FP8 && c.pipe != 0;
+  const int smem = ((c.wn == 4 || pipe) ? 3 : 2) * 64 * (2 + c.wn) * 128;
+  auto go = [&](auto kern, int threads) {
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    kern<<<grid, 512, smem, stream>>>(p);
-  } else {
-    auto kern = scaled_mm_tile_kernel<out_t, FP8, 2, 2, 2>;
-    NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    kern<<<grid, 256, smem, stream>>>(p);
+    kern<<<grid, threads, smem, stream>>>(p);
+    return NMX_OK;
+  };
+  if constexpr (FP8) {
+    if (pipe) {
+      const int rc = c.wn == 4 ? go(scaled_mm_tile_kernel<out_t, true, 2, 4, 3, true>, 512)
+                               : go(scaled_mm_tile_kernel<out_t, true, 2, 2, 3, true>, 256);
+      if (rc != NMX_OK) return rc;
+    }
+  }
+  if (!pipe) {
+    const int rc = c.wn == 4 ? go(scaled_mm_tile_kernel<out_t, FP8, 2, 4, 3>, 512) : go(scaled_mm_tile_kernel<out_t, FP8, 2, 2, 2>, 256);
+    if (rc != NMX_OK) return rc;
   }
   NMX_LAUNCH_CHECK();
   if (p.k_splits > 1 && !p.defer_reduce) {
@@ -893,7 +984,7 @@ extern "C" int nmx_scaled_int8_quant(void* out, const void* input, float* scales
 
 extern "C" int64_t nmx_scaled_mm_scratch_bytes(int m, int n, int k) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
-  const int sp = mm_use_tile(m, n, k) ? mm_tile_cfg(m, n, k).splits : mm_splits(m, n, k);
+  const int sp = mm_use_tile(m, n, k) ? std::max(mm_tile_cfg(m, n, k, true).splits, mm_tile_cfg(m, n, k, false).splits) : mm_splits(m, n, k);
   return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
 }
 
