@@ -51,14 +51,7 @@ constexpr int kWImg = kWN * 2048;            // per column group [k-tile pair q 
 constexpr int kSImg = kWN * 256;             // per column group 64 fp16 scales (+ the 128 bytes the upper lanes deposit)
 constexpr int kSlot = kAImg + kWImg + kSImg;
 
-#if (NMX_DABLATE & 128)
-__device__ unsigned long long g_dma_dbg[4096][4];
-__device__ unsigned long long g_dma_end[4096];  // per workgroup: shader-clock cycles and 100 MHz ticks around the main loop
-#endif
 
-#if (NMX_DABLATE & 128)
-static int g_dbg_nwg = 0;
-#endif
 struct DmaParams {
   const void* a;
   const int32_t* b;
@@ -96,10 +89,6 @@ struct WRaw { uint32_t r[4][4]; };    // [chunk m][word t] of k-tile g, already 
 // every wave doing both, those holds came out of the MFMA issue time (timing ablation: 15-19 of 64 us on gate_up at M = 256).
 template <bool SCALED, bool LS>
 __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
-#if (NMX_DABLATE & 128)
-  unsigned long long tec, ter;
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tec), "=s"(ter)::"memory");
-#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wn = wave & (kWN - 1), kg = wave / kWN;
@@ -298,10 +287,6 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
 
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-#if (NMX_DABLATE & 128)
-  unsigned long long t0c, t0r, t1c, t1r;
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0c), "=s"(t0r)::"memory");
-#endif
   auto body = [&](auto cur_c, int it) {
     constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % kNBUF, PRV = (CUR + 2) % kNBUF;
     const char* const buf = ring + CUR * kSlot;
@@ -412,16 +397,6 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
     if (it + 2 >= per) break;
     body(I2{}, it + 2);
   }
-#if (NMX_DABLATE & 128)
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1c), "=s"(t1r)::"memory");
-  if (threadIdx.x == 0) {
-    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
-    g_dma_dbg[wg & 4095][0] = t1c - t0c;
-    g_dma_dbg[wg & 4095][1] = t1r - t0r;
-    g_dma_dbg[wg & 4095][2] = t0r - ter;   // entry -> loop start
-    g_dma_dbg[wg & 4095][3] = ter;         // absolute entry time
-  }
-#endif
   // nothing may land in LDS after this point (clamped DMAs past the range included): the ring becomes the reduction buffer
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // the s_nop covers the MFMA -> VALU read distance that hipcc does not know about (the MFMAs are asm statements)
@@ -521,13 +496,6 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
       }
     }
   }
-#if (NMX_DABLATE & 128)
-  {
-    unsigned long long tzr, tzc;
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tzc), "=s"(tzr)::"memory");
-    if (lane == 0 && wave == 0) g_dma_end[(blockIdx.x + gridDim.x * blockIdx.y) & 4095] = tzr;
-  }
-#endif
 }
 
 
@@ -921,40 +889,10 @@ static int nmx_dma_launch(NmxWideCall& call, int splits, int xcd_split, hipStrea
   else { if (ls) NMX_DMA_LAUNCH(false, true) else NMX_DMA_LAUNCH(false, false) }
 #undef NMX_DMA_LAUNCH
   NMX_LAUNCH_CHECK();
-#if (NMX_DABLATE & 128)
-  g_dbg_nwg = std::min<int>(4096, grid.x * grid.y);
-#endif
   call.splits_done = splits;
   return NMX_OK;
 }
 
-#if (NMX_DABLATE & 128)
-// debug builds only: the stamps of the LAST launch (call after a sync; tools/lean_sweep.py does when the symbol exists)
-extern "C" void nmx_dma_dbg_dump(void) {
-  {
-    static unsigned long long h[4096][4];
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dma_dbg), sizeof(h));
-    const int nwg = g_dbg_nwg;
-    static unsigned long long he[4096];
-    hipMemcpyFromSymbol(he, HIP_SYMBOL(g_dma_end), sizeof(he));
-    double lmax = 0, emaxend = 0;
-    double sc = 0, sr = 0, sp = 0;
-    unsigned long long emin = ~0ull, emax = 0, endmax = 0;
-    int n = 0;
-    for (int i = 0; i < nwg; ++i) if (h[i][1] > 0) {
-      sc += (double)h[i][0]; sr += (double)h[i][1]; sp += (double)h[i][2]; ++n;
-      emin = std::min(emin, h[i][3]); emax = std::max(emax, h[i][3]); endmax = std::max(endmax, h[i][3] + h[i][2] + h[i][1]);
-      lmax = std::max(lmax, (double)h[i][1]);
-    }
-    for (int i = 0; i < nwg; ++i) if (h[i][1] > 0 && he[i] > emin) emaxend = std::max(emaxend, (double)(he[i] - emin));
-    fprintf(stderr, "[dma dbg] max loop %.2f us; first entry -> last kernel end (wave 0 stores drained) %.2f us\n", lmax / 100.0, emaxend / 100.0);
-    if (n)
-      fprintf(stderr, "[dma dbg] wgs=%d loop: %.0f cycles, %.2f us, clock %.3f GHz; entry->loop %.2f us; entries spread %.2f us; first entry -> last loop end %.2f us\n",
-              n, sc / n, sr / n / 100.0, sc / sr / 10.0, sp / n / 100.0, (emax - emin) / 100.0, (endmax - emin) / 100.0);
-  }
-}
-#endif
 
 // fp16 int4, channel-wise or 64-multiple groups, N a multiple of 64, K of 64; 32-bit offsets
 static bool dma_supported(int M, int N, int K, int num_groups, int group_size, int kind, int is_bf16) {
@@ -984,7 +922,11 @@ bool nmx_dma_pick(int M, int N, int K, int num_groups, int group_size, int kind,
   // the 64-row tiles on the matrices that need K splits (down at M = 256: 35.4 vs 38.6-41.6 us, qkv at M = 512: 37.1 vs 44.4, o at
   // M = 512 / 1024: 26.0 / 39.7 vs 28.8 / 45.8, down at M = 512: 59.4 vs 68.3) and level (+-2 %) where the tiles alone fill the
   // chip (gate_up from M = 256, everything at M = 2048). One row block (M <= 128) and short K per split (o at M = 256: 8
-  // splits x 4 stages 18.3-19.4 vs 17.3-18.8 us) stay with the older kernels.
+  // splits x 4 stages 18.3-19.4 vs 17.3-18.8 us) stay with the older kernels. (Round 3, late: a 64-row form of this kernel - MT = 4,
+  // the conversion ops four per MFMA - was built and measured for M <= 64: a K-group stage costs ~2,100 cycles against ~3,000 for
+  // 128 rows, so it only levels with marlin_gemm_kernel - qkv 13.3 vs 13.2 us, gate_up 26.3 vs 27.4, o 11.9 vs 9.4, down 21.5 vs
+  // 19.0 at M = 64 - and the batch-64 step was slower with it, 4.69 vs 4.56 ms, because two K splits lose gate_up's fused
+  // activation epilogue; removed again. gpurun_out/dma_small2.txt is quoted in profiles/r03_dma_sweep.txt.)
   if (M <= 128) return false;
   // batch <= 256 of the decode step: only the long-K matrices. In the step the slabs of a K split are summed by the consumer op,
   // so MORE splits than the older dispatch takes cost there what they save here (bench.py A/B at batch 256 with qkv on 4
