@@ -1801,6 +1801,21 @@ int launch_skinny(GemmParams& p, void* scratch, int64_t scratch_bytes, hipStream
     }
     if (use_large(p, false)) return launch_large<scalar_t, KIND>(p, scratch, scratch_bytes, stream);
   }
+  if constexpr (SP) {
+    // 2:4-sparse, M > 64: the wide tiles with the sparse MFMA (marlin_wide_kernel<SP = true>, round 3)
+    NmxWideCfg wc;
+    if (nmx_wide_pick(p.M, p.N, p.K, p.num_groups, p.group_size, &wc, KIND, true)) {
+      NmxWideCall call;
+      call.a = p.a; call.b = p.b; call.scales = p.scales; call.c = p.c; call.scratch = scratch; call.scratch_bytes = scratch_bytes;
+      call.M = p.M; call.N = p.N; call.K = p.K; call.num_groups = p.num_groups; call.group_size = p.group_size;
+      call.kind = KIND; call.is_bf16 = 0;
+      call.defer_reduce = p.defer_reduce;
+      call.meta = p.meta;
+      const int rc = nmx_wide_launch(call, wc, stream);
+      p.k_splits = call.splits_done;
+      return rc;
+    }
+  }
   GemmCfg cfg = pick_cfg(p.M, p.N, p.K);
   p.k_splits = cfg.splits;
   if (p.k_splits > 1) {

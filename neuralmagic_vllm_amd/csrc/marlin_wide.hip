@@ -95,10 +95,19 @@ __device__ __forceinline__ void dq_op(const u32x2& q0, const u32x2& q1, const u3
   }
 }
 
-template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MTP>
+// SP = true (round 3): 2:4-sparse weights (gptq_marlin_24_gemm; fp16, int4 / int8) on the same tile machinery. A k-step is
+// then ONE row of the packed tensor (32 dense k: the lane's words hold, per column tile, the two kept values of quads g and
+// g + 4) plus the lane's 16 bytes of metadata, the MFMA is v_smfmac_f32_16x16x32_f16 on the compressed operand (index
+// register built from the metadata, one byte selected per tile), the activations are staged so that lane group g holds
+// k = 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 of the k-step, and an accumulator row r of tile x = 2 p + q is column
+// 8 (4 (g & 1) + r) + 2 (g >> 1) + p + 4 q of the 64-column group - all exactly as marlin_gemm_kernel<SP = true> has them
+// (marlin_kernel.h; reference marlin_24_cuda_kernel.cu:111-860, common/mma.h:39-82). Half the conversion work and half
+// the weight bytes of the dense launch per flop; compiler-scheduled conversion (no hand-placed plan).
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MTP, bool SP = false>
 __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const GemmParams p) {
+  static_assert(!SP || (__is_same(scalar_t, f16) && KIND != W_FP8), "2:4 path: fp16, int4 / int8 weights");
   constexpr bool I4 = (KIND == W_INT4);
-  constexpr bool FAST = I4 && __is_same(scalar_t, f16);  // hand-placed conversion; other kinds: compiler-scheduled
+  constexpr bool FAST = I4 && __is_same(scalar_t, f16) && !SP;  // hand-placed conversion; other kinds: compiler-scheduled
   constexpr bool SCALED = (MODE == 1);
   constexpr int MT = MTP;                       // 16-row MFMA tiles per wave: 8 (128-row wave tile) or 4 (64 rows, M <= 64)
   constexpr int NTILE = 4;                      // 16-column MFMA tiles per wave
@@ -110,6 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // load issue order per iteration: [batch(s + 2)] [W(2 s + 5)] [W(2 s + 6)]; hipcc derives the counted vmcnt waits
   static_assert((NA == 2 || NA == 4 || NA == 8) && NA <= MT, "activation pieces per thread");
   using bvec_t = typename std::conditional<I4, u32x2, u32x4>::type;
+  using mvec_t = typename std::conditional<SP, u32x4, bvec_t>::type;  // second half of a k-step: k-tile row 2 ks + 1 / the metadata
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // Fused silu_and_mul (p.act_out, host guarantees no K split and (N / 2) % (64 WN) == 0): the tile is 32 WN gate columns
   // PLUS the 32 WN up columns N / 2 further right - column groups wn < WN / 2 stream gate weights, the others the
   // matching up weights, and the epilogue pairs them through LDS.
-  const bool fuse_act = p.act_out != nullptr;
+  const bool fuse_act = !SP && p.act_out != nullptr;  // (the host never asks the 2:4 launch for the fused activation)
   const int n0 = fuse_act ? (wn >= WN / 2 ? N / 2 : 0) + (tile_x * (WN / 2) + (wn % (WN / 2))) * 64 : (tile_x * WN + wn) * 64;
   const bool col_ok = n0 < N;
   const int m0 = block_m * BM;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   };
 
   // ---- descriptors and per-lane offsets ----
-  const int ktiles = K / 16;
+  const int ktiles = SP ? K / 32 : K / 16;       // rows of the packed tensor (2:4: one row = 32 dense k)
   const int row_bytes = N * (I4 ? 8 : 16);       // one k-tile row of the packed tensor
   // Every vector-memory load is a compiler-visible buffer intrinsic: hipcc counts the waits itself and never reads a
   // destination early. (Inline-asm loads with "+v" destinations were tried first: under register pressure the allocator
@@ -187,6 +197,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.scales), 0, p.num_groups * N * (int)sizeof(scalar_t), 0x00020000);
   // weights: lane (g, hi, c8) reads words 2 hi, 2 hi + 1 (int4; 4 words for 8-bit) of chunk 4 c8 + g of both k-tile rows
   const int b_voff = (((col_ok ? n0 : 0) / 64) * WORDS64 + (4 * c8 + g) * (I4 ? 4 : 8) + (I4 ? 2 : 4) * hi) * 4;
+  // 2:4 metadata: the lane's 8 reordered int16 (tile x = 2 p + q, k-half cc at 4 p + 2 cc + q) start at int16 index
+  // 2 (row N + n0 + 32 hi + 4 c8) (format_24.py:21-50 solved for this lane's columns, as in marlin_gemm_kernel)
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(SP ? p.meta : (const void*)p.b), 0, SP ? ktiles * N * 4 : 0, 0x00020000);
+  const int m_voff = (((col_ok ? n0 : 0) + 32 * hi + 4 * c8) * 2) * 2;
   // activations: piece i of this thread = row i * (TS / 8) + (tis >> 3), 16-byte chunk cc8 = tis & 7 of the 128-byte
   // stage row: a wave instruction reads 8 rows x one whole 128-byte line
   const int tis = (wave % (WM * WN)) * 64 + lane;
@@ -199,11 +213,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // LDS image: fragment (k-step ks, lane group g, row) = 16 bytes at ((ks * 4 + g) * BM + (row ^ 4 ks)) * 16; dword e2 of
   // piece (row, ks, cc) is dword cc of fragment (ks, g = e2, row). The row ^ 4 ks swizzle puts the two k-steps that one
   // ds_write_b32 wave-half covers on disjoint banks; the 16 row-lanes of a fragment read stay 16 distinct slots.
-  char* const w_base = abuf + ((aks * 4) * BM + ((tis >> 3) ^ (4 * aks))) * 16 + 4 * acc_;
+  // 2:4: lane group g multiplies quads g and g + 4 of the k-step: dword e2 of chunk cc (k = 8 cc + 2 e2 + {0, 1}) is dword
+  // 2 (cc >> 1) + (e2 & 1) of fragment (ks, g = 2 (cc & 1) + (e2 >> 1), row)
+  char* const w_base = SP ? abuf + ((aks * 4 + 2 * (acc_ & 1)) * BM + ((tis >> 3) ^ (4 * aks))) * 16 + 8 * (acc_ >> 1)
+                          : abuf + ((aks * 4) * BM + ((tis >> 3) ^ (4 * aks))) * 16 + 4 * acc_;
   // scales (MODE 1): the lane's four tile columns c8 + 8 t + 32 hi sit at positions 8 c8 + 4 hi + t (scale_perm)
   const int s_voff = (int)((((col_ok ? n0 : 0) / 64) * 64 + 8 * c8 + 4 * hi) * sizeof(scalar_t));
 
-  struct BStep { bvec_t q0, q1; };
+  struct BStep { bvec_t q0; mvec_t q1; };
   // k-step j of this slice lives in ring[j % RD]. 128-row wave tiles: 4 slots (2 stages ahead; the registers are the
   // accumulators'). 64-row wave tiles have registers to spare and run where the weight stream is the bound (M <= 64 ...
   // 256 on small matrices): 8 slots = 7 k-steps (7 KiB per wave, 56 KiB per CU) of weights in flight - tools/probes/
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   u32x2 scc = {0, 0}, scn = {0, 0};              // packed scale rows (4 halves = the lane's 4 tiles) of the current / next stage
   WFrag wfa, wfb;                                // dequantised fragments of the even / odd k-step of a stage
 #pragma unroll
-  for (int i = 0; i < RD; ++i) { ring[i].q0 = bvec_t{}; ring[i].q1 = bvec_t{}; }
+  for (int i = 0; i < RD; ++i) { ring[i].q0 = bvec_t{}; ring[i].q1 = mvec_t{}; }
 #pragma unroll
   for (int i = 0; i < NA; ++i) areg[i] = u32x4{0, 0, 0, 0};
 
@@ -229,9 +246,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // walk positions it will need next in SGPRs (wpos[], advanced once per iteration by walk_advance) - stage_of() per load
   // was 29 scalar instructions per k-step, a quarter of the loop's instruction stream at 64 rows.
   auto issue_w = [&](int stage, int ks, BStep& r) {  // k-step ks of absolute stage `stage`
-    const int soff = 2 * (2 * stage + ks) * row_bytes;  // never past the tensor
+    const int soff = (SP ? 1 : 2) * (2 * stage + ks) * row_bytes;  // never past the tensor
     if constexpr ((NMX_WABLATE & 64) != 0) return;
-    if constexpr (I4) {
+    if constexpr (SP) {
+      if constexpr (I4) r.q0 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff, 0);
+      else r.q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, soff, 0);
+      r.q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_m, m_voff, (2 * stage + ks) * N * 4, 0);
+    } else if constexpr (I4) {
       r.q0 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff, NMX_WIDE_NT ? 2 : 0);
       r.q1 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, b_voff, soff + row_bytes, NMX_WIDE_NT ? 2 : 0);
     } else {
@@ -293,7 +314,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     if constexpr ((NMX_WABLATE & 16) != 0) return;
     char* wb = w_base + buf * A_IMG + i * (TS / 8) * 16;
 #pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) *reinterpret_cast<uint32_t*>(wb + e2 * BM * 16) = areg[i][e2];
+    for (int e2 = 0; e2 < 4; ++e2) {
+      if constexpr (SP) *reinterpret_cast<uint32_t*>(wb + (e2 >> 1) * BM * 16 + 4 * (e2 & 1)) = areg[i][e2];
+      else *reinterpret_cast<uint32_t*>(wb + e2 * BM * 16) = areg[i][e2];
+    }
   };
   auto stage_barrier = [&]() {
     if constexpr ((NMX_WABLATE & 8) != 0) __builtin_amdgcn_wave_barrier();
@@ -302,6 +326,25 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 
   // whole k-step conversion, compiler-scheduled (prologue; and every k-step of the kinds without a hand-placed plan)
   auto dequant_cxx = [&](const BStep& r, const u32x2& sc, WFrag& f) {
+    if constexpr (SP) {
+      // f.w[t] = {kept values of quad g, of quad g + 4, index register, -}: index byte 0 (ABID 0) = positions for tile 2 p,
+      // byte 2 (ABID 2) = tile 2 p + 1; low nibble = quad g (k-half 0), high nibble = quad g + 4 (k-half 1)
+      uint32_t xidx[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        const uint32_t m0 = r.q1[2 * pp] >> (4 * g), m1 = (r.q1[2 * pp + 1] >> (4 * g)) << 4;
+        xidx[pp] = (m0 & 0x000f000fu) | (m1 & ~0x000f000fu);
+      }
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        // tile x = t = 2 p + q: column 8 c8 + 2 hi + p + 4 q. int4: word p, block q 8 bits up; 8-bit: word 2 p + q
+        const uint32_t w = I4 ? (r.q0[t >> 1] >> (8 * (t & 1))) : r.q0[t];
+        Dequant<scalar_t, KIND>::run(w, SCALED ? scale_operand(sc, t) : 0u, SCALED, f.w[t][0], f.w[t][1]);
+        f.w[t][2] = xidx[t >> 1];
+        f.w[t][3] = 0;
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
       const uint32_t s2t = SCALED ? scale_operand(sc, t) : 0u;
@@ -348,7 +391,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         const int i = mt * NTILE + t;
         // builtin MFMA here: the compiler pads the VALU-write -> MFMA-read distance of its own conversion code
         if constexpr ((NMX_WABLATE & 1) != 0) acc[mt][t][0] += __builtin_bit_cast(float, wq[t][mt & 3] ^ af[mt][t & 3]);
-        else acc[mt][t] = mfma_16x16x32<scalar_t>(wq[t], af[mt], acc[mt][t]);
+        else if constexpr (SP) {
+          const f16x4 wa = __builtin_bit_cast(f16x4, u32x2{wq[t][0], wq[t][1]});
+          const f16x8 ab = __builtin_bit_cast(f16x8, af[mt]);
+          if (t & 1) acc[mt][t] = __builtin_amdgcn_smfmac_f32_16x16x32_f16(wa, ab, acc[mt][t], (int)wq[t][2], 0, 2);
+          else acc[mt][t] = __builtin_amdgcn_smfmac_f32_16x16x32_f16(wa, ab, acc[mt][t], (int)wq[t][2], 0, 0);
+        } else acc[mt][t] = mfma_16x16x32<scalar_t>(wq[t], af[mt], acc[mt][t]);
         (void)dummy; (void)i;
       }
       // fragment read 4 row tiles ahead: af[mt + 4] of this k-step, or (KS = 0) af[mt - 4] of k-step 1
@@ -508,7 +556,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       for (int r = 0; r < 4; ++r) {
         const int col = 32 * (g >> 1) + 8 * t + 4 * (g & 1) + r;
         const int cc = col & 7, b = col >> 3;
-        const float sv = Scalar<scalar_t>::to_f32(sc[32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3)]);
+        // (2:4: marlin_24_scale_perm_single is the identity; D row r of tile x = 2 p + q is column 8 (4 (g & 1) + r) + 2 (g >> 1) + p + 4 q)
+        const int pos = SP ? 8 * (4 * (g & 1) + r) + 2 * (g >> 1) + (t >> 1) + 4 * (t & 1) : 32 * (b >> 2) + 8 * (cc >> 1) + (cc & 1) + 2 * (b & 3);
+        const float sv = Scalar<scalar_t>::to_f32(sc[pos]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][t][r] *= sv;
       }
@@ -576,6 +626,30 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   }
   if (wk != 0 || !col_ok) return;
 
+  if constexpr (SP) {
+    // tiles q and 2 + q are neighbouring columns -> 2-element stores (as marlin_gemm_kernel<SP>)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + wm * 16 * MT + mt * 16 + li;
+      if (m >= M) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int n = n0 + 8 * (4 * (g & 1) + r) + 2 * (g >> 1) + 4 * q;
+          const float v0 = acc[mt][q][r], v1 = acc[mt][2 + q][r];
+          if (p.k_splits == 1) {
+            union { scalar_t h[2]; uint32_t u; } o;
+            o.h[0] = Scalar<scalar_t>::from_f32(v0);
+            o.h[1] = Scalar<scalar_t>::from_f32(v1);
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = o.u;
+          } else {
+            *reinterpret_cast<f32x2*>(p.partial + ((int64_t)split_id * M + m) * N + n) = f32x2{v0, v1};
+          }
+        }
+    }
+    return;
+  }
   // lane (g, li): D rows = 4 consecutive output columns 32 (g >> 1) + 8 t + 4 (g & 1) + r, D col = activation row li
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -596,7 +670,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   }
 }
 
-template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MT = 8>
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MT = 8, bool SP = false>
 int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM;
   const size_t stage = (size_t)WK * 2 * BM * 128;
@@ -604,7 +678,7 @@ int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
   const size_t ex = (size_t)WM * (WN / 2) * MT * 4 * 64 * 8;  // fused silu_and_mul: the up halves as fp16 / bf16
   const size_t smem = std::max(std::max(stage, red), ex);
   dim3 grid(ceil_div(ceil_div(p.N, 64 * WN), 8) * 8 * ceil_div(p.M, BM), p.k_splits, 1);
-  auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK, MT>;
+  auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK, MT, SP>;
   if (smem > 64 * 1024)
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   kern<<<grid, 64 * WM * WN * WK, smem, stream>>>(p);
@@ -626,6 +700,25 @@ int launch_wide_shape(const GemmParams& p, const NmxWideCfg& c, hipStream_t stre
   if (c.wm == 2 && c.wn == 4) return launch_wide_cfg<scalar_t, KIND, MODE, 2, 4, 1>(p, stream);
   if (c.wm == 1 && c.wn == 2) return launch_wide_cfg<scalar_t, KIND, MODE, 1, 2, 4>(p, stream);
   return launch_wide_cfg<scalar_t, KIND, MODE, 1, 4, 2>(p, stream);
+}
+
+// 2:4-sparse launches: fp16, int4 / int8; 128-row wave tiles as 1 x 4 x 2 or 1 x 2 x 4 waves, 64-row wave tiles (int4) as 1 x 2 x 4
+template <int KIND>
+int launch_wide_sparse(const GemmParams& p, const NmxWideCfg& c, hipStream_t stream) {
+  if (p.num_groups > 1) {
+    if (c.mt == 4) {
+      if constexpr (KIND == W_INT4) return launch_wide_cfg<f16, KIND, 1, 1, 2, 4, 4, true>(p, stream);
+      else return NMX_ERR_UNSUPPORTED;
+    }
+    if (c.wn == 2) return launch_wide_cfg<f16, KIND, 1, 1, 2, 4, 8, true>(p, stream);
+    return launch_wide_cfg<f16, KIND, 1, 1, 4, 2, 8, true>(p, stream);
+  }
+  if (c.mt == 4) {
+    if constexpr (KIND == W_INT4) return launch_wide_cfg<f16, KIND, 0, 1, 2, 4, 4, true>(p, stream);
+    else return NMX_ERR_UNSUPPORTED;
+  }
+  if (c.wn == 2) return launch_wide_cfg<f16, KIND, 0, 1, 2, 4, 8, true>(p, stream);
+  return launch_wide_cfg<f16, KIND, 0, 1, 4, 2, 8, true>(p, stream);
 }
 
 template <typename scalar_t, int KIND>
@@ -658,13 +751,15 @@ WideEnv wide_env() {
 
 }  // namespace
 
-bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg, int kind) {
+bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg, int kind, bool sparse) {
   const WideEnv env = wide_env();
   if (env.off || K % 64 != 0 || N % 64 != 0) return false;
   // M <= 64: the 64-row instantiation wins only where 128-column tiles alone fill the chip and K is short (gate_up at
   // 32 < M <= 64: 29.3 vs 34.5 us); qkv / o / down need K splits and stay on the row-block / decode kernels
   const bool small_ok = M > 32 && K <= 8192 && ceil_div(N, 128) >= 192;
   if (M <= 64 && (kind != W_INT4 || !(env.set ? env.mt == 4 : small_ok))) return false;  // 64-row tiles: int4 only
+  // 2:4-sparse (round 3): M > 64, K a multiple of 64; group sizes -1 / 128 are the op's own restriction
+  if (sparse && (M <= 64 || kind == W_FP8)) return false;
   if (num_groups > 1 && group_size % 64 != 0) return false;
   if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)K * N >= (1ll << 31) || (int64_t)num_groups * N * 2 >= (1ll << 31)) return false;
   NmxWideCfg c;
@@ -702,10 +797,15 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
       // long K, few tiles: K splits across workgroups down to 14 stages per wave (down_proj at M = 256: 32 tiles x 8 splits,
       // 36.1 us against 42.8 on the row-block kernel, deferred reduce; M = 192: 34.1 vs 38.4; at M = 128 the 16 tiles do
       // not fill the chip and the row-block kernel stays)
-      if (K < 8192 || units < 32) return false;
+      // (2:4-sparse: from 64 tiles - down_proj at M = 256 stays on the row-block kernel, 37.7 vs 38.8-40.6 us; M = 512: 59.8 vs 63.1)
+      if (K < 8192 || units < (sparse ? 64 : 32)) return false;
       while (units * c.splits * 2 <= 256 && stages / (c.splits * 2 * 2) >= 14) c.splits *= 2;
       if (units * c.splits < 192) return false;
     }
+  }
+  if (sparse) {  // instantiated shapes: 1 x 4 x 2 and 1 x 2 x 4 waves (128-row wave tiles), 1 x 2 x 4 with 64-row wave tiles (int4)
+    if (c.wm != 1) { c.wm = 1; }
+    if (c.mt == 4 && (kind != W_INT4 || c.wn != 2)) c.mt = 8;
   }
   c.wk = 8 / (c.wm * c.wn);
   while (c.splits > 1 && stages / (c.splits * c.wk) < 1) c.splits /= 2;
@@ -715,14 +815,14 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
 
 int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream) {
   GemmParams p;
-  p.a = call.a; p.b = call.b; p.meta = nullptr; p.zeros = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
+  p.a = call.a; p.b = call.b; p.meta = call.meta; p.zeros = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
   p.M = call.M; p.N = call.N; p.K = call.K; p.num_groups = call.num_groups; p.group_size = call.group_size;
   p.slow_act_order = 0;
   if (const char* e = nmx_tune(NMX_TUNE_GEMM_XCD_SPLIT)) p.xcd_split = atoi(e) != 0;
   p.defer_reduce = call.defer_reduce;
   p.k_splits = cfg.splits;
   // fused silu_and_mul epilogue: only a launch whose workgroups own whole K (the slabs of a K split belong to the consumer)
-  call.act_done = (call.act_out != nullptr && cfg.splits == 1 && call.N % 2 == 0 && (call.N / 2) % (64 * cfg.wn) == 0) ? 1 : 0;
+  call.act_done = (call.meta == nullptr && call.act_out != nullptr && cfg.splits == 1 && call.N % 2 == 0 && (call.N / 2) % (64 * cfg.wn) == 0) ? 1 : 0;
   p.act_out = call.act_done ? call.act_out : nullptr;
   if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to the splits that fit
     const int64_t per = (int64_t)p.M * p.N * sizeof(float);
@@ -734,6 +834,10 @@ int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream
 #ifdef NMX_WIDE_MIN  // experiment builds: fp16 int4 only (compile time)
   rc = launch_wide_kind<f16, W_INT4>(p, cfg, stream);
 #else
+  if (call.meta != nullptr) {
+    if (call.is_bf16 || call.kind == W_FP8) return NMX_ERR_UNSUPPORTED;
+    rc = call.kind == W_INT4 ? launch_wide_sparse<W_INT4>(p, cfg, stream) : launch_wide_sparse<W_INT8>(p, cfg, stream);
+  } else
 #define NMX_WIDE_KIND(T)                                                            \
   switch (call.kind) {                                                              \
     case W_INT4: rc = launch_wide_kind<T, W_INT4>(p, cfg, stream); break;            \

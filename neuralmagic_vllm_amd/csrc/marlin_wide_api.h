@@ -19,13 +19,14 @@ struct NmxWideCall {
   int splits_done;        // out: K splits the launch used
   void* act_out = nullptr;  // [M, N / 2]: fuse silu_and_mul into the epilogue when the launch has no K split (see act_done)
   int act_done = 0;         // out: act_out was written (and c was not)
+  const void* meta = nullptr;  // 2:4-sparse weights (gptq_marlin_24_gemm): the reordered metadata tensor; b is then the compressed tensor
 };
 
 // tile configuration of marlin_wide_kernel: wm x wn x wk waves, `splits` K splits across workgroups
 struct NmxWideCfg { int wm, wn, wk, splits, mt; };  // mt = 16-row tiles per wave (8; 4 = 64-row wave tiles)
 
 // true when the wide kernel handles this problem (M large enough, plain layout); fills the configuration
-__attribute__((visibility("hidden"))) bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg, int kind = 0);  // kind: WeightKind (0 = int4)
+__attribute__((visibility("hidden"))) bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideCfg* cfg, int kind = 0, bool sparse = false);  // kind: WeightKind (0 = int4)
 __attribute__((visibility("hidden"))) int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream);
 
 // marlin_dma_kernel (marlin_dma.hip): fp16 int4 GEMM with both operands delivered by LDS-DMA. nmx_dma_pick: true when it

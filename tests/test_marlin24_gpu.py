@@ -102,6 +102,35 @@ def test_llama3_8b_shapes_sparse24(ops, K, N, M):
     assert torch.equal(d.materialize().float().cpu(), c)
 
 
+@pytest.mark.parametrize("wide", ["1,4,1", "1,4,2", "1,2,1", "1,2,2", "1,2,2,4", None])
+@pytest.mark.parametrize("num_bits,group", [(4, -1), (4, 128), (8, -1), (8, 128)])
+@pytest.mark.parametrize("M,N,K", [(65, 256, 256), (128, 512, 512), (200, 384, 1024), (256, 1024, 448), (300, 128, 2048)])
+def test_marlin_24_wide_kernel(ops, tune, M, N, K, num_bits, group, wide):
+    """Round 3: marlin_wide_kernel<SP = true> (M > 64: 128-row / 64-row wave tiles on the sparse MFMA) in every instantiated
+    shape - forced through NMX_GEMM_WIDE, K splits included, ragged rows, padding column groups, K / 64 odd - against the
+    row-block kernel (NMX_GEMM_WIDE=0) on the same random compressed words + valid metadata, and both against fp32 torch."""
+    if group != -1 and K % group != 0:
+        pytest.skip("K not a multiple of the group")
+    if wide is not None and wide.endswith(",4") and num_bits != 4:
+        pytest.skip("64-row wave tiles: int4 only")
+    gen = torch.Generator().manual_seed(M + N + K + num_bits)
+    pack = 32 // num_bits
+    mq = torch.randint(-2**31, 2**31 - 1, (K // 32, N * 16 // pack), dtype=torch.int32, generator=gen).to(DEV)
+    meta = random_valid_meta(K // 32, N * 2, gen).to(DEV)
+    groups = 1 if group == -1 else K // group
+    ms = (torch.rand(groups, N, generator=gen) * 0.01 + 0.005).to(torch.float16).to(DEV)
+    a = torch.randn(M, K, dtype=torch.float16, generator=gen).to(DEV)
+    ws = workspace24(N)
+    tune(NMX_GEMM_WIDE="0")
+    base = ops.gptq_marlin_24_gemm(a, mq, meta, ms, ws, num_bits, M, N, K).float()
+    tune(NMX_GEMM_WIDE=wide)
+    out = ops.gptq_marlin_24_gemm(a, mq, meta, ms, ws, num_bits, M, N, K).float()
+    torch.cuda.synchronize()
+    assert compute_max_diff(out.cpu(), base.cpu()) < TOL
+    d = ops.gptq_marlin_24_gemm_deferred(a, mq, meta, ms, ws, num_bits, M, N, K)
+    assert torch.equal(d.materialize().float(), out)
+
+
 def test_marlin_24_errors(ops):
     a = torch.zeros(1, 128, dtype=torch.float16, device=DEV)
     q = torch.zeros(4, 256, dtype=torch.int32, device=DEV)
