@@ -74,6 +74,7 @@ extern "C" int64_t nmx_marlin_gemm_scratch_bytes(int size_m, int size_n, int siz
   NmxWideCfg wc;  // channel-wise and 64-multiple groups pick the same tile shape
   if (nmx_wide_pick(size_m, size_n, size_k, 1, size_k, &wc)) splits = std::max(splits, wc.splits);
   else if (size_m > 128 && ceil_div(size_n, 256) * ceil_div(size_m, 256) >= 192) splits = std::max(splits, large_splits(size_m, size_n, size_k));
+  if (nmx_wide_pick(size_m, size_n, size_k, 1, size_k, &wc, 0, true)) splits = std::max(splits, wc.splits);  // gptq_marlin_24_gemm shares this sizing
   int ds = 1;  // marlin_dma_kernel (fp16 int4; the dtype is not known here)
   if (nmx_dma_pick(size_m, size_n, size_k, 1, size_k, 0, 0, &ds)) splits = std::max(splits, ds);
   return splits > 1 ? (int64_t)splits * size_m * size_n * sizeof(float) : 0;

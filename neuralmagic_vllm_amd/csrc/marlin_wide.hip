@@ -97,9 +97,9 @@ __device__ __forceinline__ void dq_op(const u32x2& q0, const u32x2& q1, const u3
 
 // SP = true (round 3): 2:4-sparse weights (gptq_marlin_24_gemm; fp16, int4 / int8) on the same tile machinery. A k-step is
 // then ONE row of the packed tensor (32 dense k: the lane's words hold, per column tile, the two kept values of quads g and
-// g + 4) plus the lane's 16 bytes of metadata, the MFMA is v_smfmac_f32_16x16x32_f16 on the compressed operand (index
-// register built from the metadata, one byte selected per tile), the activations are staged so that lane group g holds
-// k = 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 of the k-step, and an accumulator row r of tile x = 2 p + q is column
+// g + 4) plus the lane's 16 bytes of metadata; the MFMA is v_smfmac_f32_16x16x64_f16 on the compressed operands of BOTH
+// k-steps of a stage (index register built from the metadata, 16 bits selected per tile); the activations are staged in
+// fragments (k-step, g') = k 4 g' .. 4 g' + 3 and 16 + 4 g' .. 16 + 4 g' + 3; an accumulator row r of tile x = 2 p + q is column
 // 8 (4 (g & 1) + r) + 2 (g >> 1) + p + 4 q of the 64-column group - all exactly as marlin_gemm_kernel<SP = true> has them
 // (marlin_kernel.h; reference marlin_24_cuda_kernel.cu:111-860, common/mma.h:39-82). Half the conversion work and half
 // the weight bytes of the dense launch per flop; compiler-scheduled conversion (no hand-placed plan).
@@ -231,6 +231,15 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   u32x2 sraw = {0, 0};
   u32x2 scc = {0, 0}, scn = {0, 0};              // packed scale rows (4 halves = the lane's 4 tiles) of the current / next stage
   WFrag wfa, wfb;                                // dequantised fragments of the even / odd k-step of a stage
+  // 2:4: one v_smfmac_f32_16x16x64_f16 per (row tile, column tile) and STAGE - twice the products per matrix-pipe cycle of the
+  // 32-k form (tools/probes/smfmac_rate_probe.hip: every fp16 MFMA form issues at ~16-17 cycles). Its operands are the two
+  // k-steps' compressed values side by side - {ks 0: quad g, quad g + 4, ks 1: quad g, quad g + 4}, index fields in the same
+  // order (16 bits per tile, the half selected with ABID) - but the 64-k form pairs them with the activation operand ACROSS
+  // lane groups (one-hot experiments, tools/probes/run_smfmac_probe.py: pair pa of lane group ga multiplies 4-k slot
+  // 2 (ga >> 1) + (pa & 1) of activation lane group 2 (ga & 1) + (pa >> 1)). Activation lane group gb therefore supplies, of
+  // k-step gb & 1, the staged fragments (gb >> 1) and (gb >> 1) + 2 - the staging layout itself is the 32-k form's.
+  struct SFrag { uint32_t a[4][4]; uint32_t idx[2]; };
+  SFrag sfa, sfb;                                // (SP) operands of the current / the next stage, roles swap every stage
 #pragma unroll
   for (int i = 0; i < RD; ++i) { ring[i].q0 = bvec_t{}; ring[i].q1 = mvec_t{}; }
 #pragma unroll
@@ -326,25 +335,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 
   // whole k-step conversion, compiler-scheduled (prologue; and every k-step of the kinds without a hand-placed plan)
   auto dequant_cxx = [&](const BStep& r, const u32x2& sc, WFrag& f) {
-    if constexpr (SP) {
-      // f.w[t] = {kept values of quad g, of quad g + 4, index register, -}: index byte 0 (ABID 0) = positions for tile 2 p,
-      // byte 2 (ABID 2) = tile 2 p + 1; low nibble = quad g (k-half 0), high nibble = quad g + 4 (k-half 1)
-      uint32_t xidx[2];
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        const uint32_t m0 = r.q1[2 * pp] >> (4 * g), m1 = (r.q1[2 * pp + 1] >> (4 * g)) << 4;
-        xidx[pp] = (m0 & 0x000f000fu) | (m1 & ~0x000f000fu);
-      }
-#pragma unroll
-      for (int t = 0; t < NTILE; ++t) {
-        // tile x = t = 2 p + q: column 8 c8 + 2 hi + p + 4 q. int4: word p, block q 8 bits up; 8-bit: word 2 p + q
-        const uint32_t w = I4 ? (r.q0[t >> 1] >> (8 * (t & 1))) : r.q0[t];
-        Dequant<scalar_t, KIND>::run(w, SCALED ? scale_operand(sc, t) : 0u, SCALED, f.w[t][0], f.w[t][1]);
-        f.w[t][2] = xidx[t >> 1];
-        f.w[t][3] = 0;
-      }
-      return;
-    }
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
       const uint32_t s2t = SCALED ? scale_operand(sc, t) : 0u;
@@ -365,6 +355,25 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     }
   };
 
+  auto dequant_sp64 = [&](const BStep& r0, const BStep& r1, const u32x2& sc, SFrag& f) {
+    if constexpr (SP) {
+      uint32_t x0[2], x1[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {  // per k-step: byte 0 = tile 2 p, byte 2 = tile 2 p + 1 (low nibble quad g, high nibble quad g + 4)
+        x0[pp] = ((r0.q1[2 * pp] >> (4 * g)) & 0x000f000fu) | (((r0.q1[2 * pp + 1] >> (4 * g)) << 4) & 0x00f000f0u);
+        x1[pp] = ((r1.q1[2 * pp] >> (4 * g)) & 0x000f000fu) | (((r1.q1[2 * pp + 1] >> (4 * g)) << 4) & 0x00f000f0u);
+        f.idx[pp] = x0[pp] | (x1[pp] << 8);   // half 0 = tile 2 p: {ks 0 byte, ks 1 byte}, half 1 = tile 2 p + 1
+      }
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        const uint32_t s2t = SCALED ? scale_operand(sc, t) : 0u;
+        const uint32_t w0 = I4 ? (r0.q0[t >> 1] >> (8 * (t & 1))) : r0.q0[t];
+        const uint32_t w1 = I4 ? (r1.q0[t >> 1] >> (8 * (t & 1))) : r1.q0[t];
+        Dequant<scalar_t, KIND>::run(w0, s2t, SCALED, f.a[t][0], f.a[t][1]);
+        Dequant<scalar_t, KIND>::run(w1, s2t, SCALED, f.a[t][2], f.a[t][3]);
+      }
+    }
+  };
   const uint32_t magic = 0x64006400u, neg72 = 0xd480d480u;
   const char* const r_base0 = abuf + (g * BM + wm * 16 * MT + li) * 16;
   const char* const r_base1 = abuf + ((4 + g) * BM + wm * 16 * MT + (li ^ 4)) * 16;
@@ -391,12 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         const int i = mt * NTILE + t;
         // builtin MFMA here: the compiler pads the VALU-write -> MFMA-read distance of its own conversion code
         if constexpr ((NMX_WABLATE & 1) != 0) acc[mt][t][0] += __builtin_bit_cast(float, wq[t][mt & 3] ^ af[mt][t & 3]);
-        else if constexpr (SP) {
-          const f16x4 wa = __builtin_bit_cast(f16x4, u32x2{wq[t][0], wq[t][1]});
-          const f16x8 ab = __builtin_bit_cast(f16x8, af[mt]);
-          if (t & 1) acc[mt][t] = __builtin_amdgcn_smfmac_f32_16x16x32_f16(wa, ab, acc[mt][t], (int)wq[t][2], 0, 2);
-          else acc[mt][t] = __builtin_amdgcn_smfmac_f32_16x16x32_f16(wa, ab, acc[mt][t], (int)wq[t][2], 0, 0);
-        } else acc[mt][t] = mfma_16x16x32<scalar_t>(wq[t], af[mt], acc[mt][t]);
+        else acc[mt][t] = mfma_16x16x32<scalar_t>(wq[t], af[mt], acc[mt][t]);
         (void)dummy; (void)i;
       }
       // fragment read 4 row tiles ahead: af[mt + 4] of this k-step, or (KS = 0) af[mt - 4] of k-step 1
@@ -476,6 +480,48 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     if constexpr (LAND) load_piece(NA - 1, wpos[0], st + 2 < nst);
   };
 
+  // 2:4 stage: MT x 4 sparse MFMAs of 64 k on `cur`, in their shadow the conversion of the NEXT stage's two k-steps (ring slots
+  // ra, rb -> `out`), the fragment reads two row tiles ahead, and the next stage's activation batch + the ring refills exactly
+  // as kstep_block places them
+  auto stage_sp = [&](const SFrag& cur, SFrag& out, BStep& ra, BStep& rb, const u32x2& s2, int buf, int st) {
+    if constexpr (SP) {
+      typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+      typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+      const char* rb0 = abuf + buf * A_IMG + (((4 * (g & 1) + (g >> 1)) * BM + wm * 16 * MT + (li ^ (4 * (g & 1)))) * 16);
+      const char* rb1 = rb0 + 2 * BM * 16;
+      u32x4 a0[MT], a1[MT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        a0[mt] = *reinterpret_cast<const u32x4*>(rb0 + mt * 256);
+        a1[mt] = *reinterpret_cast<const u32x4*>(rb1 + mt * 256);
+      }
+      dequant_sp64(ra, rb, s2, out);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const u32x8 b8 = u32x8{a0[mt][0], a0[mt][1], a0[mt][2], a0[mt][3], a1[mt][0], a1[mt][1], a1[mt][2], a1[mt][3]};
+        const f16x16 bb = __builtin_bit_cast(f16x16, b8);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          const f16x8 wa = __builtin_bit_cast(f16x8, u32x4{cur.a[t][0], cur.a[t][1], cur.a[t][2], cur.a[t][3]});
+          if (t & 1) acc[mt][t] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wa, bb, acc[mt][t], (int)cur.idx[t >> 1], 0, 1);
+          else acc[mt][t] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(wa, bb, acc[mt][t], (int)cur.idx[t >> 1], 0, 0);
+        }
+        if (mt + 2 < MT) {
+          a0[mt + 2] = *reinterpret_cast<const u32x4*>(rb0 + (mt + 2) * 256);
+          a1[mt + 2] = *reinterpret_cast<const u32x4*>(rb1 + (mt + 2) * 256);
+        }
+        constexpr int STEP = MT / NA;
+        if (mt % STEP == 0) write_piece(mt / STEP, buf ^ 1);
+        if (mt % STEP == 0 && mt >= STEP) load_piece(mt / STEP - 1, wpos[0], st + 2 < nst);
+        if (mt == 1) issue_w(wpos[NCUR - 1], 0, ra);  // k-steps 2 st + 2 + RD, 2 st + 3 + RD: stage st + 1 + RD / 2
+        // keeps the fragment reads two row tiles ahead (hipcc otherwise hoists all 2 MT of them to the top: 64 registers, spills)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      load_piece(NA - 1, wpos[0], st + 2 < nst);
+      issue_w(wpos[NCUR - 1], 1, rb);
+    }
+  };
+
   // ---- prologue, in the steady-state issue order ----
   if constexpr (SCALED) scc = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(stage_of(0)), 0);
   issue_w(stage_of(0), 0, ring[0]);
@@ -485,7 +531,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 #pragma unroll
   for (int i = 0; i < NA; ++i) write_piece(i, 0);
   scn = sraw;
-  dequant_cxx(ring[0], scc, wfa);
+  if constexpr (SP) {
+    dequant_sp64(ring[0], ring[1], scc, sfa);
+    issue_w(stage_of((RD + 1) >> 1), 1, ring[1]);  // slot 1 is free again: k-step RD + 1
+  } else dequant_cxx(ring[0], scc, wfa);
   // the same order as an iteration issues them: hipcc merges the pending-load state of this path and of the loop's back
   // edge at the loop head, and any difference turns the first waits of the body into vmcnt(0)
   issue_w(stage_of((RD - 1) >> 1), 1, ring[RD - 1]);
@@ -503,6 +552,18 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     const int st = it;  // relative stage of the walk
     BStep& r1 = ring[(2 * PH + 1) % RD];
     BStep& r2 = ring[(2 * PH + 2) % RD];
+    if constexpr (SP) {
+      BStep& ra = ring[(2 * PH + 2) % RD];
+      BStep& rb = ring[(2 * PH + 3) % RD];
+      if constexpr (PAR == 0) stage_sp(sfa, sfb, ra, rb, scn, PAR, st);
+      else stage_sp(sfb, sfa, ra, rb, scn, PAR, st);
+      scc = scn;
+      scn = sraw;
+      load_scale(wpos[1]);
+      walk_advance(st);
+      stage_barrier();
+      return;
+    }
     u32x4 af[MT + 4];  // 0..7: k-step 0, 8..11: first four of k-step 1 (then 4..7 again)
     if constexpr ((NMX_WABLATE & 4) == 0) {
 #pragma unroll
@@ -783,6 +844,8 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
   } else if (M <= 128 && K <= 8192 && ceil_div(N, 128) >= 192) {
     // gate_up-like at 64 < M <= 128: one row block, 128-column tiles fill the chip without a split (41.0 vs 47.9 us)
     c.wm = 1; c.wn = 2; c.splits = 1;
+    // (2:4-sparse: 256-column tiles with two K splits - 35.9 vs 45.2 us at M = 128, row-block kernel 42.7)
+    if (sparse) { c.wn = 4; c.splits = 2; }
   } else {
     // Measured (tools/lean_sweep.py, 32-launch graph chains over distinct weights, Llama-3-8B shapes, M = 128 .. 2048;
     // gpurun_out/wide_sweep.log): 128-row x 256-column tiles with two K slices per workgroup win 13-23 % over the 64-row
@@ -797,8 +860,7 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
       // long K, few tiles: K splits across workgroups down to 14 stages per wave (down_proj at M = 256: 32 tiles x 8 splits,
       // 36.1 us against 42.8 on the row-block kernel, deferred reduce; M = 192: 34.1 vs 38.4; at M = 128 the 16 tiles do
       // not fill the chip and the row-block kernel stays)
-      // (2:4-sparse: from 64 tiles - down_proj at M = 256 stays on the row-block kernel, 37.7 vs 38.8-40.6 us; M = 512: 59.8 vs 63.1)
-      if (K < 8192 || units < (sparse ? 64 : 32)) return false;
+      if (K < 8192 || units < 32) return false;
       while (units * c.splits * 2 <= 256 && stages / (c.splits * 2 * 2) >= 14) c.splits *= 2;
       if (units * c.splits < 192) return false;
     }

@@ -1,5 +1,5 @@
 // Issue rate of the sparse / dense fp16 MFMA forms on gfx950: one wave per SIMD, 16 independent accumulators, 4096 instructions
-// each; prints cycles per instruction (s_memtime, shader clock). Build: hipcc --offload-arch=gfx950 -O3 -o exp/smfmac_rate_probe tools/probes/smfmac_rate_probe.hip
+// each, 1 / 2 / 4 waves per SIMD; prints cycles per instruction and SIMD (s_memtime, shader clock). Build: hipcc --offload-arch=gfx950 -O3 -o exp/smfmac_rate_probe tools/probes/smfmac_rate_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -8,7 +8,7 @@ typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int KIND>
-__global__ __launch_bounds__(256) void rate(float* out, unsigned long long* cyc, int iters) {
+__global__ __launch_bounds__(1024) void rate(float* out, unsigned long long* cyc, int iters) {
   f32x4 acc[16];
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
   f16x8 a8, b8;
@@ -31,25 +31,27 @@ __global__ __launch_bounds__(256) void rate(float* out, unsigned long long* cyc,
   const unsigned long long t1 = __builtin_readcyclecounter();
   float s = 0;
   for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
+  out[blockIdx.x * 1024 + threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
 template <int KIND>
 void run(const char* name) {
   float* out; unsigned long long* cyc;
-  hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&cyc, 1024 * 8);
+  hipMalloc(&out, 1024 * 1024 * 4); hipMalloc(&cyc, 1024 * 8);
   const int iters = 256;
+  for (int threads : {256, 512, 1024})   // 1, 2, 4 waves per SIMD
   for (int wgs : {1, 256}) {
-    rate<KIND><<<wgs, 256>>>(out, cyc, iters);
+    rate<KIND><<<wgs, threads>>>(out, cyc, iters);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    rate<KIND><<<wgs, 256>>>(out, cyc, iters);
+    rate<KIND><<<wgs, threads>>>(out, cyc, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
-    printf("%-28s wgs %3d: %.2f us per launch, %.1f ns per instruction per SIMD (wall), s_memtime ticks per instruction %.2f\n", name, wgs, ms * 1e3,
-           ms * 1e6 / (iters * 16.0), (double)h / (iters * 16.0));
+    const double per_simd = iters * 16.0 * (threads / 256);
+    printf("%-28s %d waves/SIMD, wgs %3d: %.2f us per launch, %.2f ns per instruction and SIMD (wall), %.1f shader cycles per instruction and SIMD\n", name,
+           threads / 256, wgs, ms * 1e3, ms * 1e6 / per_simd, (double)h / per_simd);
   }
 }
 int main() {
