@@ -818,9 +818,12 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
   // M <= 64: the 64-row instantiation wins only where 128-column tiles alone fill the chip and K is short (gate_up at
   // 32 < M <= 64: 29.3 vs 34.5 us); qkv / o / down need K splits and stay on the row-block / decode kernels
   const bool small_ok = M > 32 && K <= 8192 && ceil_div(N, 128) >= 192;
-  if (M <= 64 && (kind != W_INT4 || !(env.set ? env.mt == 4 : small_ok))) return false;  // 64-row tiles: int4 only
+  // (2:4-sparse, round 3: also qkv-like matrices whose 128-column tiles x 4 K splits fill the chip - 12.9 vs 15.2 us at M = 64;
+  // o_proj, 32 tiles, stays on the row-block kernel: 11.6 vs 10.4)
+  const bool small_sparse = sparse && M > 32 && K <= 4096 && ceil_div(N, 128) * 4 >= 160 && ceil_div(N, 128) * 4 <= 256;
+  if (M <= 64 && (kind != W_INT4 || !(env.set ? env.mt == 4 : (small_ok || small_sparse)))) return false;  // 64-row tiles: int4 only
   // 2:4-sparse (round 3): M > 64, K a multiple of 64; group sizes -1 / 128 are the op's own restriction
-  if (sparse && (M <= 64 || kind == W_FP8)) return false;
+  if (sparse && (M <= 32 || kind == W_FP8)) return false;
   if (num_groups > 1 && group_size % 64 != 0) return false;
   if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)K * N >= (1ll << 31) || (int64_t)num_groups * N * 2 >= (1ll << 31)) return false;
   NmxWideCfg c;
@@ -829,7 +832,7 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
   if (env.set) {
     c.wm = env.wm; c.wn = env.wn; c.splits = env.splits; c.mt = (M <= 64 || kind == W_INT4) ? env.mt : 8;
   } else if (M <= 64) {
-    c.wm = 1; c.wn = 2; c.splits = 1; c.mt = 4;
+    c.wm = 1; c.wn = 2; c.splits = small_ok ? 1 : 4; c.mt = 4;
   } else if (kind == W_INT4 && M <= 256 && K <= 4096 && N <= 8192) {
     // small matrices (qkv, o) at 64 < M <= 256: 64-row x 128-column tiles, no K split when they alone give >= 192
     // workgroups, else two (tools/lean_sweep.py: qkv 27.1 vs 31.0 us at M = 256, 21.6 vs 25.2 at 128; o 22.6 vs 24.2, 19.7 vs 23.5)
