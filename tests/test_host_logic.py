@@ -133,9 +133,13 @@ def test_split_plan_of_the_llama_shapes_is_stable():
 
     gm, mm = lib.nmx_marlin_gemm_scratch_bytes, lib.nmx_scaled_mm_scratch_bytes
     # (K, N): qkv, o, gate_up, down of Llama-3-8B
-    assert [splits(gm, 1, 6144, 4096), splits(gm, 64, 6144, 4096)] == [2, 2]
+    # (the query is the maximum over the dense and the 2:4-sparse plan: sparse qkv at 32 < M <= 64 runs 4 splits on the wide tiles)
+    assert [splits(gm, 1, 6144, 4096), splits(gm, 64, 6144, 4096)] == [2, 4]
     assert [splits(gm, 1, 4096, 4096), splits(gm, 64, 4096, 4096)] == [4, 4]
     assert [splits(gm, 1, 28672, 4096), splits(gm, 64, 28672, 4096)] == [0, 0]   # gate_up: enough column tiles, no split
     assert splits(gm, 64, 4096, 14336) == 8
     assert gm(0, 4096, 4096) == 0 and mm(0, 4096, 4096) == 0
     assert [splits(mm, 64, 6144, 4096), splits(mm, 64, 28672, 4096), splits(mm, 64, 4096, 14336)] == [2, 0, 4]
+    # batch 256 (the bench default): int4 / sparse qkv, o, gate_up, down and the fp8 tile kernel's plan
+    assert [splits(gm, 256, n, k) for n, k in ((6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336))] == [2, 4, 0, 8]
+    assert [splits(mm, 256, n, k) for n, k in ((6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336))] == [2, 4, 0, 8]
