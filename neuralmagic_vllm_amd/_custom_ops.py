@@ -51,11 +51,18 @@ def _stream(t: torch.Tensor) -> c_vp:
     # One process per GPU: the library launches on the CURRENT HIP device (kernel attributes, error state, scratch are
     # per device). The reference wraps every op in an OptionalCUDAGuard (e.g. gptq_marlin.cu:1745); here a tensor on
     # another device is refused loudly instead of being launched against the wrong device's state.
+    # (the raw getters: torch.cuda.current_stream() builds a Stream object per call - ~3 of the ~5 us an op call costs the
+    # host in eager mode)
     idx = t.device.index
-    if idx is not None and idx != torch.cuda.current_device():
-        raise RuntimeError(f"tensor on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: "
+    cur = _raw_device()
+    if idx is not None and idx != cur:
+        raise RuntimeError(f"tensor on cuda:{idx} but the current device is cuda:{cur}: "
                            "wrap the call in torch.cuda.device(tensor.device)")
-    return c_vp(torch.cuda.current_stream(t.device).cuda_stream)
+    return c_vp(_raw_stream(cur))
+
+
+_raw_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
 
 
 def is_custom_op_supported(op_name: str) -> bool:
