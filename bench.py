@@ -101,6 +101,7 @@ def parse():
     ap.add_argument("--attn", choices=["auto", "v1", "v2"], default="auto", help="decode attention op: auto = the reference's rule "
                     "(paged_attn.py:120-121)")
     ap.add_argument("--no-act-fuse", action="store_true", help="int4: gate_up GEMM and silu_and_mul as two ops (A/B of the fused epilogue)")
+    ap.add_argument("--no-attn-absmax", action="store_true", help="fp8: separate absmax pass over the attention output (A/B of paged_attention_v1/v2_absmax)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report batch 1/8/64/256 decode and the int4 GEMM TFLOP/s table")
@@ -151,6 +152,7 @@ class Llama3Decode:
         self.all_reduce, self.all_gather = all_reduce, all_gather  # tensor-parallel collectives (None: TP = 1)
         self.fuse = False  # int4 only: deferred split-K reduction + rotary / cache fusion (set by main)
         self.act_fuse = True  # int4: gate_up + silu_and_mul as one op (set by main)
+        self.attn_absmax = True  # fp8: paged attention leaves the maxima of its output (set by main)
         self.n_layers = n_layers
         self.variant = variant
         self.kv_dtype = VARIANTS[variant]["kv"]
@@ -248,10 +250,19 @@ class Llama3Decode:
             return ops.awq_marlin_gemm(x, w[0], w[1], w[2], x.shape[0], N, K)
         return ops.awq_gemm(x, w[0], w[2], w[1], 8)
 
-    def attention(self, q, layer):
+    def attention(self, q, layer, want_absmax=False):
         cfg = self.cfg
         kc, vc = self.kv[layer]
         out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        if want_absmax:  # fp8 W8A8: the output's maxima as a by-product (o_proj's dynamic quantisation is then one launch)
+            if self.use_v1:
+                amax = self.ops.paged_attention_v1_absmax(out, q, kc, vc, cfg["kv_heads"], self.scale, self.block_tables,
+                                                          self.seq_lens, self.BS, self.L, None, self.kv_dtype, self.kv_scale)
+            else:
+                amax = self.ops.paged_attention_v2_absmax(out, self.exp_sums, self.max_logits, self.tmp_out, q, kc, vc,
+                                                          cfg["kv_heads"], self.scale, self.block_tables, self.seq_lens, self.BS,
+                                                          self.L, None, self.kv_dtype, self.kv_scale)
+            return out, amax
         if self.use_v1:
             self.ops.paged_attention_v1(out, q, kc, vc, cfg["kv_heads"], self.scale, self.block_tables, self.seq_lens,
                                         self.BS, self.L, None, self.kv_dtype, self.kv_scale)
@@ -313,8 +324,8 @@ class Llama3Decode:
         per-token |max| of its output, so the dynamic activation quantisation is one launch instead of absmax + quantise
         (scaled_fp8_quant_partials: same scale and codes); the fp8 GEMMs leave their K-split slabs AND their scale epilogue
         to the consumer (cutlass_scaled_mm_deferred + the *_splitk_scaled ops: no reduce launch); rotary + KV-cache write
-        are one launch. o_proj's input comes out of paged attention and keeps the two-launch quantisation.
-        Bit-identical to step() (tests/test_fused_gpu.py)."""
+        are one launch. Round 3: paged attention leaves the maxima of its output too (paged_attention_v1/v2_absmax), so no
+        stand-alone absmax launch is left in the step. Bit-identical to step() (tests/test_fused_gpu.py)."""
         cfg, ops = self.cfg, self.ops
         nh, nkv, D = cfg["heads"], cfg["kv_heads"], cfg["head"]
 
@@ -330,8 +341,11 @@ class Llama3Decode:
             kc, vc = self.kv[li]
             qkv = ops.rope_reshape_and_cache(self.positions, mm(x, amax, lw["qkv"]), nh, nkv, D, self.cos_sin_cache, kc, vc,
                                              self.slot_mapping, self.kv_dtype, self.kv_scale)
-            a = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li)
-            h, amax = ops.fused_add_rms_norm_splitk(mm(a.view(-1, nh * D), None, lw["o"]), resid, lw["ln2"], 1e-5, want_absmax=True)
+            if self.attn_absmax:
+                a, amax = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li, want_absmax=True)
+            else:  # A/B: the two-launch quantisation of o_proj's input (absmax pass + quantise)
+                a, amax = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li), None
+            h, amax = ops.fused_add_rms_norm_splitk(mm(a.view(-1, nh * D), amax, lw["o"]), resid, lw["ln2"], 1e-5, want_absmax=True)
             gu = mm(h, amax, lw["gate_up"])
             act = torch.empty(h.shape[0], cfg["inter"], dtype=h.dtype, device=h.device)
             amax = ops.silu_and_mul_splitk(act, gu, want_absmax=True)
@@ -608,6 +622,7 @@ def main():
     # reduce launch until there are >= 128 rows (measured: batch 64 7.81 vs 7.71 ms, batch 256 12.61 vs 13.28 ms)
     awq_fusable = args.config.startswith("awq70b") and not args.awq_op and args.batch >= 128
     model.act_fuse = not args.no_act_fuse
+    model.attn_absmax = not args.no_attn_absmax
     model.fuse = (args.config in ("int4", "fp8", "sparse24") or awq_fusable) and not args.no_fuse and (args.config != "fp8" or tp == 0)
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()

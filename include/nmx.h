@@ -79,6 +79,27 @@ int nmx_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* 
                            int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
                            int bs_head_sliding_step, nmx_stream_t stream);
 
+/* paged_attention_v1 / v2 with the output's absolute maxima as a by-product (no reference counterpart: the fp8 W8A8 path of
+ * vllm/model_executor/layers/quantization/fp8.py:231-259 quantises o_proj's input with ops.scaled_fp8_quant(x, None), whose
+ * first pass is this maximum). absmax: float32 [nmx_paged_attention_absmax_numel(...)], every entry written; the maximum over
+ * all entries equals max |out| exactly. fp16 / bf16 queries. Consumer: nmx_scaled_fp8_quant_partials. */
+int nmx_paged_attention_absmax_numel(int num_seqs, int num_heads, int num_kv_heads, int partitioned);
+int nmx_paged_attention_v1_absmax(void* out, float* absmax, const void* query, const void* key_cache, const void* value_cache,
+                                  int num_seqs, int num_heads, int num_kv_heads, int head_size, int block_size,
+                                  int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                                  const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                                  int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale,
+                                  int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
+                                  int bs_head_sliding_step, nmx_stream_t stream);
+int nmx_paged_attention_v2_absmax(void* out, float* absmax, float* exp_sums, float* max_logits, void* tmp_out,
+                                  const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+                                  int num_heads, int num_kv_heads, int head_size, int block_size, int64_t q_stride,
+                                  int64_t kv_block_stride, int64_t kv_head_stride, float scale, const int32_t* block_tables,
+                                  int max_num_blocks_per_seq, const int32_t* seq_lens, int max_seq_len,
+                                  const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
+                                  int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
+                                  nmx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * KV-cache ops. Replace csrc/cache_kernels.cu (schema csrc/torch_bindings.cpp:207-244, csrc/cache.h:8-32).
  * ---------------------------------------------------------------------------------------------------------- */

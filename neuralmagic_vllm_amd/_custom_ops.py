@@ -259,6 +259,33 @@ def paged_attention_v2(
                  blocksparse_block_size, blocksparse_head_sliding_step)
 
 
+def paged_attention_v1_absmax(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size,
+                              max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank=0, blocksparse_local_blocks=0,
+                              blocksparse_vert_stride=0, blocksparse_block_size=64, blocksparse_head_sliding_step=0) -> torch.Tensor:
+    """paged_attention_v1 that also returns partial maxima of |out| (float32; their maximum is out.abs().max() exactly) for
+    scaled_fp8_quant_partials: the fp8 W8A8 step then has no absmax pass over the attention output."""
+    n = _lib.lib().nmx_paged_attention_absmax_numel(c_int(query.shape[0]), c_int(query.shape[1]), c_int(num_kv_heads), c_int(0))
+    amax = torch.empty(n, dtype=torch.float32, device=query.device)
+    _attn_common(_lib.lib().nmx_paged_attention_v1_absmax, (_p(out), _p(amax)), query, key_cache, value_cache, num_kv_heads,
+                 scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
+                 blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step)
+    return amax
+
+
+def paged_attention_v2_absmax(out, exp_sum, max_logits, tmp_out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                              seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank=0,
+                              blocksparse_local_blocks=0, blocksparse_vert_stride=0, blocksparse_block_size=64,
+                              blocksparse_head_sliding_step=0) -> torch.Tensor:
+    """paged_attention_v2 with the same by-product (one maximum per head and sequence, written by the reduce kernel)."""
+    n = _lib.lib().nmx_paged_attention_absmax_numel(c_int(query.shape[0]), c_int(query.shape[1]), c_int(num_kv_heads), c_int(1))
+    amax = torch.empty(n, dtype=torch.float32, device=query.device)
+    _attn_common(_lib.lib().nmx_paged_attention_v2_absmax, (_p(out), _p(amax), _p(exp_sum), _p(max_logits), _p(tmp_out)), query,
+                 key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
+                 kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                 blocksparse_head_sliding_step)
+    return amax
+
+
 # ---------------------------------------------------------------------------------------------------------
 # KV-cache ops (vllm/_custom_ops.py:370-412)
 # ---------------------------------------------------------------------------------------------------------

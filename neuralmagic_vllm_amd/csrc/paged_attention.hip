@@ -56,6 +56,9 @@ struct AttnParams {
   int max_blocks_per_seq, block_size, bs_shift;
   int partitioned, max_num_partitions;
   int sparse, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step;
+  // optional (nmx_paged_attention_v1/v2_absmax): max |out| of what a workgroup (v1: one per kv head x q tile x sequence) / the
+  // v2 reduce (one per head x sequence) wrote, so that a dynamic fp8 quantisation of the attention output needs no absmax pass
+  float* absmax;
 };
 
 template <typename scalar_t>
@@ -396,8 +399,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
   const int t = threadIdx.x;
   const int cq = t & 15;            // query row within the tile
   const int cq_row = qt * 16 + cq;
-  if (cq_row >= p.q_per_kv) return;
-  const int chead = kvh * p.q_per_kv + cq_row;
+  const bool active = cq_row < p.q_per_kv;  // (idle rows of the tile stay for the absmax barrier)
+  const int chead = kvh * p.q_per_kv + min(cq_row, p.q_per_kv - 1);
   float M = -FLT_MAX;
 #pragma unroll
   for (int w = 0; w < NW; ++w) M = fmaxf(M, lds_m[w * 16 + cq]);
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
   if (p.partitioned) {
     const int64_t pidx = ((int64_t)seq * p.num_heads + chead) * p.max_num_partitions + part;
     outp = reinterpret_cast<scalar_t*>(p.out) + pidx * D;
-    if ((t >> 4) == 0) {
+    if ((t >> 4) == 0 && active) {
       p.max_logits[pidx] = M;
       p.exp_sums[pidx] = L;
     }
@@ -421,18 +424,36 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
     outp = reinterpret_cast<scalar_t*>(p.out) + ((int64_t)seq * p.num_heads + chead) * D;
   }
   // thread handles d = 4 * (t >> 4) + {0..3}, stepping by 4 * (NW * 4)
-  for (int d0 = 4 * (t >> 4); d0 < D; d0 += 16 * NW) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
+  if (active) {
+    for (int d0 = 4 * (t >> 4); d0 < D; d0 += 16 * NW) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + ((int64_t)w * 16 + cq) * D + d0);
-      acc += v * f[w];
+      for (int w = 0; w < NW; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + ((int64_t)w * 16 + cq) * D + d0);
+        acc += v * f[w];
+      }
+      acc *= inv;
+      union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
+        amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(r.h[j])));  // of the ROUNDED output: what a later absmax pass would see
+      }
+      *reinterpret_cast<u32x2*>(outp + d0) = r.u;
     }
-    acc *= inv;
-    union { scalar_t h[4]; u32x2 u; } r;
+  }
+  if (p.absmax != nullptr && !p.partitioned) {  // (uniform) one maximum per workgroup
+    amax = wave_reduce_max(amax);
+    __syncthreads();  // everyone is done with lds_m
+    if (lane == 0) lds_m[wave] = amax;
+    __syncthreads();
+    if (t == 0) {
+      float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
-    *reinterpret_cast<u32x2*>(outp + d0) = r.u;
+      for (int w = 0; w < NW; ++w) m = fmaxf(m, lds_m[w]);
+      p.absmax[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    }
   }
 }
 
@@ -683,8 +704,8 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
   const int t = threadIdx.x;
   const int cq = t & 15;            // query row within the tile
   const int cq_row = qt * 16 + cq;
-  if (cq_row >= p.q_per_kv) return;
-  const int chead = kvh * p.q_per_kv + cq_row;
+  const bool active = cq_row < p.q_per_kv;  // (idle rows of the tile stay for the absmax barrier)
+  const int chead = kvh * p.q_per_kv + min(cq_row, p.q_per_kv - 1);
   float M = -FLT_MAX;
 #pragma unroll
   for (int w = 0; w < NW; ++w) M = fmaxf(M, lds_m[w * 16 + cq]);
@@ -700,7 +721,7 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
   if (p.partitioned) {
     const int64_t pidx = ((int64_t)seq * p.num_heads + chead) * p.max_num_partitions + part;
     outp = reinterpret_cast<scalar_t*>(p.out) + pidx * D;
-    if ((t >> 4) == 0) {
+    if ((t >> 4) == 0 && active) {
       p.max_logits[pidx] = M;
       p.exp_sums[pidx] = L;
     }
@@ -708,18 +729,36 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
     outp = reinterpret_cast<scalar_t*>(p.out) + ((int64_t)seq * p.num_heads + chead) * D;
   }
   // thread handles d = 4 * (t >> 4) + {0..3}, stepping by 4 * (NW * 4)
-  for (int d0 = 4 * (t >> 4); d0 < D; d0 += 16 * NW) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
+  if (active) {
+    for (int d0 = 4 * (t >> 4); d0 < D; d0 += 16 * NW) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + ((int64_t)w * 16 + cq) * D + d0);
-      acc += v * f[w];
+      for (int w = 0; w < NW; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + ((int64_t)w * 16 + cq) * D + d0);
+        acc += v * f[w];
+      }
+      acc *= inv;
+      union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
+        amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(r.h[j])));  // of the ROUNDED output: what a later absmax pass would see
+      }
+      *reinterpret_cast<u32x2*>(outp + d0) = r.u;
     }
-    acc *= inv;
-    union { scalar_t h[4]; u32x2 u; } r;
+  }
+  if (p.absmax != nullptr && !p.partitioned) {  // (uniform) one maximum per workgroup
+    amax = wave_reduce_max(amax);
+    __syncthreads();  // everyone is done with lds_m
+    if (lane == 0) lds_m[wave] = amax;
+    __syncthreads();
+    if (t == 0) {
+      float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
-    *reinterpret_cast<u32x2*>(outp + d0) = r.u;
+      for (int w = 0; w < NW; ++w) m = fmaxf(m, lds_m[w]);
+      p.absmax[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    }
   }
 }
 
@@ -730,15 +769,23 @@ __global__ void paged_attention_v2_reduce_kernel(scalar_t* __restrict__ out, con
                                                  const float* __restrict__ max_logits,
                                                  const scalar_t* __restrict__ tmp_out,
                                                  const int32_t* __restrict__ seq_lens, int max_num_partitions,
-                                                 int head_size) {
+                                                 int head_size, float* __restrict__ absmax) {
   const int head = blockIdx.x, num_heads = gridDim.x, seq = blockIdx.y;
   const int seq_len = seq_lens[seq];
   const int np = (seq_len + kPartitionSize - 1) / kPartitionSize;
   const int64_t pb = ((int64_t)seq * num_heads + head) * max_num_partitions;
   scalar_t* o = out + ((int64_t)seq * num_heads + head) * head_size;
   const scalar_t* tp = tmp_out + pb * head_size;
+  float amax = 0.f;
   if (np <= 1) {
-    for (int i = threadIdx.x; i < head_size; i += blockDim.x) o[i] = tp[i];
+    for (int i = threadIdx.x; i < head_size; i += blockDim.x) {
+      o[i] = tp[i];
+      amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(tp[i])));
+    }
+    if (absmax != nullptr) {
+      amax = wave_reduce_max(amax);
+      if (threadIdx.x == 0) absmax[(int64_t)seq * num_heads + head] = amax;
+    }
     return;
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -758,7 +805,13 @@ __global__ void paged_attention_v2_reduce_kernel(scalar_t* __restrict__ out, con
   for (int d = threadIdx.x; d < head_size; d += 64) {
     float acc = 0.f;
     for (int j = 0; j < np; ++j) acc += Scalar<scalar_t>::to_f32(tp[(int64_t)j * head_size + d]) * resc[j] * inv;
-    o[d] = Scalar<scalar_t>::from_f32(acc);
+    const scalar_t ov = Scalar<scalar_t>::from_f32(acc);
+    o[d] = ov;
+    amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(ov)));
+  }
+  if (absmax != nullptr) {
+    amax = wave_reduce_max(amax);
+    if (threadIdx.x == 0) absmax[(int64_t)seq * num_heads + head] = amax;
   }
 }
 
@@ -983,7 +1036,7 @@ int dispatch_kv(const AttnParams& p, int kv_dtype, int head_size, int num_seqs, 
   }
 }
 
-int run_attention(bool partitioned, void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
                   const void* key_cache, const void* value_cache, int num_seqs, int num_heads, int num_kv_heads,
                   int head_size, int block_size, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
                   float scale, const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
@@ -1004,6 +1057,8 @@ int run_attention(bool partitioned, void* out, float* exp_sums, float* max_logit
   if (num_seqs == 0) return NMX_OK;
 
   AttnParams p;
+  NMX_CHECK(absmax == nullptr || dtype != NMX_F32, NMX_ERR_UNSUPPORTED, "paged_attention absmax: float16 / bfloat16 queries only");
+  p.absmax = absmax;
   p.out = partitioned ? tmp_out : out;
   p.exp_sums = exp_sums;
   p.max_logits = max_logits;
@@ -1048,14 +1103,14 @@ int run_attention(bool partitioned, void* out, float* exp_sums, float* max_logit
   if (dtype == NMX_F32)
     paged_attention_v2_reduce_kernel<float><<<rgrid, 64, rsmem, stream>>>((float*)out, exp_sums, max_logits,
                                                                           (const float*)tmp_out, seq_lens, num_partitions,
-                                                                          head_size);
+                                                                          head_size, nullptr);
   else if (dtype == NMX_F16)
     paged_attention_v2_reduce_kernel<f16><<<rgrid, 64, rsmem, stream>>>((f16*)out, exp_sums, max_logits, (const f16*)tmp_out,
-                                                                        seq_lens, num_partitions, head_size);
+                                                                        seq_lens, num_partitions, head_size, absmax);
   else
     paged_attention_v2_reduce_kernel<bf16><<<rgrid, 64, rsmem, stream>>>((bf16*)out, exp_sums, max_logits,
                                                                          (const bf16*)tmp_out, seq_lens, num_partitions,
-                                                                         head_size);
+                                                                         head_size, absmax);
   NMX_LAUNCH_CHECK();
   return NMX_OK;
 }
@@ -1070,7 +1125,7 @@ extern "C" int nmx_paged_attention_v1(void* out, const void* query, const void* 
                                       int kv_dtype, float kv_scale, int tp_rank, int bs_local_blocks,
                                       int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
                                       nmx_stream_t stream) {
-  return run_attention(false, out, nullptr, nullptr, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
+  return run_attention(false, out, nullptr, nullptr, nullptr, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
                        num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
                        block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
                        kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
@@ -1086,7 +1141,49 @@ extern "C" int nmx_paged_attention_v2(void* out, float* exp_sums, float* max_log
                                       int kv_dtype, float kv_scale, int tp_rank, int bs_local_blocks,
                                       int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
                                       nmx_stream_t stream) {
-  return run_attention(true, out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+  return run_attention(true, out, nullptr, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+                       num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
+                       block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
+                       kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
+                       (hipStream_t)stream);
+}
+
+// ---- the same ops with the output's absolute maxima as a by-product (fp8 W8A8 models: o_proj's dynamic per-tensor activation
+// quantisation then needs no absmax pass over the attention output - nmx_scaled_fp8_quant_partials takes these). absmax:
+// float32 [nmx_paged_attention_absmax_numel(...)], every entry written (v1: one per kv head x q tile x sequence, v2: one per
+// head x sequence); max over all entries = max |out| exactly (taken on the rounded outputs). fp16 / bf16 queries.
+extern "C" int nmx_paged_attention_absmax_numel(int num_seqs, int num_heads, int num_kv_heads, int partitioned) {
+  if (num_seqs <= 0 || num_heads <= 0 || num_kv_heads <= 0) return 0;
+  if (partitioned) return num_seqs * num_heads;
+  const int q_per_kv = num_heads / num_kv_heads;
+  return num_seqs * num_kv_heads * ((q_per_kv + 15) / 16);
+}
+
+extern "C" int nmx_paged_attention_v1_absmax(void* out, float* absmax, const void* query, const void* key_cache,
+                                             const void* value_cache, int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                             int block_size, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                             float scale, const int32_t* block_tables, int max_num_blocks_per_seq,
+                                             const int32_t* seq_lens, int max_seq_len, const float* alibi_slopes, int dtype,
+                                             int kv_dtype, float kv_scale, int tp_rank, int bs_local_blocks, int bs_vert_stride,
+                                             int bs_block_size, int bs_head_sliding_step, nmx_stream_t stream) {
+  NMX_CHECK(absmax != nullptr, NMX_ERR_INVALID_ARG, "paged_attention_v1_absmax: absmax must be non-null");
+  return run_attention(false, out, absmax, nullptr, nullptr, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
+                       num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
+                       block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
+                       kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
+                       (hipStream_t)stream);
+}
+
+extern "C" int nmx_paged_attention_v2_absmax(void* out, float* absmax, float* exp_sums, float* max_logits, void* tmp_out,
+                                             const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+                                             int num_heads, int num_kv_heads, int head_size, int block_size, int64_t q_stride,
+                                             int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                                             const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                                             int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale,
+                                             int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
+                                             int bs_head_sliding_step, nmx_stream_t stream) {
+  NMX_CHECK(absmax != nullptr, NMX_ERR_INVALID_ARG, "paged_attention_v2_absmax: absmax must be non-null");
+  return run_attention(true, out, absmax, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
                        num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
                        block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
                        kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,

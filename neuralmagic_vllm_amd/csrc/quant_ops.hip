@@ -63,9 +63,16 @@ __global__ __launch_bounds__(1024) void fp8_quant_kernel(uint8_t* __restrict__ o
                                                          int64_t n8) {
   float sc;
   if constexpr (DYNAMIC) {
-    float m = 0.f;  // <= 64 partials from fp8_absmax_kernel, or one per token from a producer kernel (L2-resident)
-    for (int i = threadIdx.x & 63; i < nparts; i += 64) m = fmaxf(m, partial[i]);
+    // <= 64 partials from fp8_absmax_kernel, one per token from a producer kernel, or one per (kv head, sequence) from the
+    // attention kernels (2048 at batch 256): the whole workgroup reads them once (L2-resident), waves combine through LDS
+    __shared__ float wmax[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = fmaxf(m, partial[i]);
     m = wave_reduce_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0.f;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) m = fmaxf(m, wmax[w]);
     sc = m / 448.0f;
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale = sc;
   } else {

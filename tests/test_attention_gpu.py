@@ -243,3 +243,46 @@ def test_large_batch_property(ops):
     idx = [0, 37]
     o = run_oracle("v1", q[idx].cpu(), kc.cpu(), vc.cpu(), nkv, scale, bt[idx].cpu(), sl[idx].cpu(), BS, L, None, "auto", 1.0)
     torch.testing.assert_close(out1[idx].cpu().float(), o.float(), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("kv_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("nq,nkv,head_size", [(32, 8, 128), (12, 12, 64), (40, 2, 128)])  # GQA 4, MHA, 20 heads per kv head (two q tiles)
+def test_paged_attention_absmax(ops, version, kv_dtype, dtype, nq, nkv, head_size):
+    """Round 3: paged_attention_v1/v2_absmax write the SAME output bits as the plain ops and partial maxima whose maximum is
+    out.abs().max() exactly; scaled_fp8_quant_partials on them gives the codes and the scale of scaled_fp8_quant(out)."""
+    seed_all(nq + head_size)
+    block_size, num_seqs = 16, 7
+    scale = float(head_size**-0.5)
+    q = torch.empty(num_seqs, nq, head_size, dtype=dtype).uniform_(-scale, scale)
+    seq_lens = [700, 1, 33, 512, 1025, 513, 16]
+    max_len = max(seq_lens)
+    mb = (max_len + block_size - 1) // block_size
+    bt = torch.tensor([[random.randint(0, 255) for _ in range(mb)] for _ in range(num_seqs)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(256, block_size, 1, nkv, head_size, kv_dtype, dtype)
+    kv_scale = 0.75 if kv_dtype != "auto" else 1.0
+    plain = run_hip(ops, version, q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
+    qg, kc, vc, btg, slg = q.to(DEV), kcs[0].to(DEV), vcs[0].to(DEV), bt.to(DEV), sl.to(DEV)
+    out = torch.full_like(qg, float("nan"))
+    if version == "v1":
+        amax = ops.paged_attention_v1_absmax(out, qg, kc, vc, nkv, scale, btg, slg, block_size, max_len, None, kv_dtype, kv_scale)
+        assert amax.numel() == num_seqs * nkv * ((nq // nkv + 15) // 16)
+    else:
+        P = (max_len + PARTITION - 1) // PARTITION
+        tmp = torch.empty(num_seqs, nq, P, head_size, dtype=dtype, device=DEV)
+        es = torch.empty(num_seqs, nq, P, dtype=torch.float32, device=DEV)
+        ml = torch.empty(num_seqs, nq, P, dtype=torch.float32, device=DEV)
+        amax = ops.paged_attention_v2_absmax(out, es, ml, tmp, qg, kc, vc, nkv, scale, btg, slg, block_size, max_len, None,
+                                             kv_dtype, kv_scale)
+        assert amax.numel() == num_seqs * nq
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().view(torch.int16), plain.view(torch.int16))
+    assert float(amax.max()) == float(out.float().abs().max())
+    if version == "v2":  # one entry per (sequence, head)
+        assert torch.equal(amax.view(num_seqs, nq), out.float().abs().amax(dim=-1))
+    flat = out.view(num_seqs, nq * head_size)
+    q1, s1 = ops.scaled_fp8_quant_partials(flat, amax)
+    q0, s0 = ops.scaled_fp8_quant(flat)
+    assert torch.equal(s0, s1) and torch.equal(q0.view(torch.uint8), q1.view(torch.uint8))
