@@ -60,6 +60,17 @@ __device__ __forceinline__ void a_pk_mul_h(uint32_t& d, uint32_t s_v) {
   if constexpr (H == 0) asm volatile("v_pk_mul_f16 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d) : "v"(s_v));
   else asm volatile("v_pk_mul_f16 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]" : "+v"(d) : "v"(s_v));
 }
+// zero-point forms of the two fix-up operations: the constant comes from half H of a packed row, broadcast to both lanes
+template <int H>
+__device__ __forceinline__ void a_pk_add_h(uint32_t& d, uint32_t z_v) {
+  if constexpr (H == 0) asm volatile("v_pk_add_f16 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d) : "v"(z_v));
+  else asm volatile("v_pk_add_f16 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]" : "+v"(d) : "v"(z_v));
+}
+template <int H>
+__device__ __forceinline__ void a_pk_fma_h(uint32_t& d, uint32_t b_s, uint32_t c_v) {
+  if constexpr (H == 0) asm volatile("v_pk_fma_f16 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(d) : "s"(b_s), "v"(c_v));
+  else asm volatile("v_pk_fma_f16 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(d) : "s"(b_s), "v"(c_v));
+}
 __device__ __forceinline__ void a_lshr8(uint32_t& d, uint32_t q) { asm volatile("v_lshrrev_b32 %0, 8, %1" : "=v"(d) : "v"(q)); }
 
 struct WFrag { uint32_t w[4][4]; };  // four MFMA operand fragments (tile t, dword)
@@ -72,9 +83,10 @@ template <bool SCALED>
 struct DqPlan {
   static constexpr int PER_EVEN = SCALED ? 12 : 8, PER_ODD = PER_EVEN + 2, TOTAL = 2 * (PER_EVEN + PER_ODD);
 };
-template <bool SCALED, int J>
+// ZPV: per-column zero points - zc = the packed row of -(1024 + z), zh = the same + 960 = -(64 + z) (both exact in fp16)
+template <bool SCALED, int J, bool ZPV = false>
 __device__ __forceinline__ void dq_op(const u32x2& q0, const u32x2& q1, const u32x2& sc, WFrag& f, uint32_t (&tmp)[2],
-                                      uint32_t magic, uint32_t neg72) {
+                                      uint32_t magic, uint32_t neg72, const u32x2& zc = u32x2{0, 0}, const u32x2& zh = u32x2{0, 0}) {
   using P = DqPlan<SCALED>;
   constexpr int PAIR = P::PER_EVEN + P::PER_ODD;
   constexpr int tp = J / PAIR, r = J % PAIR;             // tile pair, op inside the pair
@@ -88,7 +100,10 @@ __device__ __forceinline__ void dq_op(const u32x2& q0, const u32x2& q1, const u3
     a_and_or(f.w[t][o], src, (o & 1) ? 0x00f000f0u : 0x000f000fu, magic);
   } else if constexpr (o < 8) {
     constexpr int e = o - 4;
-    if constexpr ((e & 1) == 0) a_pk_add(f.w[t][e], 0xe408e408u);       // (1024 + v) - 1032
+    if constexpr (ZPV) {
+      if constexpr ((e & 1) == 0) a_pk_add_h<t & 1>(f.w[t][e], zc[t >> 1]);              // (1024 + v) - (1024 + z)
+      else a_pk_fma_h<t & 1>(f.w[t][e], 0x2c002c00u, zh[t >> 1]);                         // (1024 + 16 v) / 16 - (64 + z)
+    } else if constexpr ((e & 1) == 0) a_pk_add(f.w[t][e], 0xe408e408u);       // (1024 + v) - 1032
     else a_pk_fma(f.w[t][e], 0x2c002c00u, neg72);                        // (1024 + 16 v) / 16 - 72
   } else {
     a_pk_mul_h<t & 1>(f.w[t][o - 8], sc[t >> 1]);  // scale of tile t = half t & 1 of word t >> 1 of the scale row
@@ -103,9 +118,13 @@ __device__ __forceinline__ void dq_op(const u32x2& q0, const u32x2& q1, const u3
 // 8 (4 (g & 1) + r) + 2 (g >> 1) + p + 4 q of the 64-column group - all exactly as marlin_gemm_kernel<SP = true> has them
 // (marlin_kernel.h; reference marlin_24_cuda_kernel.cu:111-860, common/mma.h:39-82). Half the conversion work and half
 // the weight bytes of the dense launch per flop; compiler-scheduled conversion (no hand-placed plan).
-template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MTP, bool SP = false>
+// ZP = true (round 3; fp16, int4, grouped): per-(group, column) zero points from p.zeros - AWQ weights repacked into the Marlin
+// layout (marlin_zp_gemm.hip) - with the arithmetic of marlin_gemm_kernel<ZP>: (1024 + q) - (1024 + z) exactly, one rounding by the
+// scale. The zero row travels with the scale row (same positions); the hand-placed conversion plan takes its two fix-up constants from it (dq_op<.., ZPV>).
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MTP, bool SP = false, bool ZP = false>
 __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const GemmParams p) {
   static_assert(!SP || (__is_same(scalar_t, f16) && KIND != W_FP8), "2:4 path: fp16, int4 / int8 weights");
+  static_assert(!ZP || (__is_same(scalar_t, f16) && KIND == W_INT4 && MODE == 1 && !SP), "zero points: fp16, int4, grouped scales");
   constexpr bool I4 = (KIND == W_INT4);
   constexpr bool FAST = I4 && __is_same(scalar_t, f16) && !SP;  // hand-placed conversion; other kinds: compiler-scheduled
   constexpr bool SCALED = (MODE == 1);
@@ -197,6 +216,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.scales), 0, p.num_groups * N * (int)sizeof(scalar_t), 0x00020000);
   // weights: lane (g, hi, c8) reads words 2 hi, 2 hi + 1 (int4; 4 words for 8-bit) of chunk 4 c8 + g of both k-tile rows
   const int b_voff = (((col_ok ? n0 : 0) / 64) * WORDS64 + (4 * c8 + g) * (I4 ? 4 : 8) + (I4 ? 2 : 4) * hi) * 4;
+  const __amdgpu_buffer_rsrc_t rs_z =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ZP ? p.zeros : p.scales), 0, ZP ? p.num_groups * N * (int)sizeof(scalar_t) : 0, 0x00020000);
   // 2:4 metadata: the lane's 8 reordered int16 (tile x = 2 p + q, k-half cc at 4 p + 2 cc + q) start at int16 index
   // 2 (row N + n0 + 32 hi + 4 c8) (format_24.py:21-50 solved for this lane's columns, as in marlin_gemm_kernel)
   const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(SP ? p.meta : (const void*)p.b), 0, SP ? ktiles * N * 4 : 0, 0x00020000);
@@ -230,6 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   u32x4 areg[NA];
   u32x2 sraw = {0, 0};
   u32x2 scc = {0, 0}, scn = {0, 0};              // packed scale rows (4 halves = the lane's 4 tiles) of the current / next stage
+  u32x2 zraw = {0, 0}, zcc = {0, 0}, zcn = {0, 0};  // (ZP) the matching rows of -(1024 + z)
   WFrag wfa, wfb;                                // dequantised fragments of the even / odd k-step of a stage
   // 2:4: one v_smfmac_f32_16x16x64_f16 per (row tile, column tile) and STAGE - twice the products per matrix-pipe cycle of the
   // 32-k form (tools/probes/smfmac_rate_probe.hip: every fp16 MFMA form issues at ~16-17 cycles). Its operands are the two
@@ -284,8 +306,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     const int lim = in_range ? a_lim : 0;
     areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, i * (TS / 8) < lim ? a_base : (int)0x7ff00000, soff + i * a_step, 0);
   };
-  auto load_scale = [&](int stage) {  // the scale row of absolute stage `stage`
+  auto load_scale = [&](int stage) {  // the scale row (and zero row) of absolute stage `stage`
     if constexpr (SCALED) sraw = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(stage), 0);
+    if constexpr (ZP) zraw = __builtin_amdgcn_raw_buffer_load_b64(rs_z, s_voff, scale_soff(stage), 0);
   };
   auto issue_batch = [&](int st) {  // prologue: walk position st
 #pragma unroll
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   };
 
   // whole k-step conversion, compiler-scheduled (prologue; and every k-step of the kinds without a hand-placed plan)
-  auto dequant_cxx = [&](const BStep& r, const u32x2& sc, WFrag& f) {
+  auto dequant_cxx = [&](const BStep& r, const u32x2& sc, WFrag& f, const u32x2& zr = u32x2{0, 0}) {
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
       const uint32_t s2t = SCALED ? scale_operand(sc, t) : 0u;
@@ -350,8 +373,15 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         f.w[t][0] = w0; f.w[t][1] = w1; f.w[t][2] = w0 ^ s2t; f.w[t][3] = w1;
         continue;
       }
-      Dequant<scalar_t, KIND>::run(w0, s2t, SCALED, f.w[t][0], f.w[t][1]);
-      Dequant<scalar_t, KIND>::run(w1, s2t, SCALED, f.w[t][2], f.w[t][3]);
+      if constexpr (ZP) {
+        const uint32_t zneg = scale_operand(zr, t);                                      // (-(1024 + z), -(1024 + z))
+        const uint32_t zhi = h2_bits(bits_h2(zneg) + bits_h2(0x63806380u));              // + 960 = -(64 + z), exact
+        dequant_zp_f16(w0, s2t, true, zneg, zhi, f.w[t][0], f.w[t][1]);
+        dequant_zp_f16(w1, s2t, true, zneg, zhi, f.w[t][2], f.w[t][3]);
+      } else {
+        Dequant<scalar_t, KIND>::run(w0, s2t, SCALED, f.w[t][0], f.w[t][1]);
+        Dequant<scalar_t, KIND>::run(w1, s2t, SCALED, f.w[t][2], f.w[t][3]);
+      }
     }
   };
 
@@ -382,13 +412,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   // conversion of the NEXT k-step's packed words `nxt` into `out`, the fragment reads 4 row tiles ahead (KS = 0: running
   // on into k-step 1's fragments), and (LAND) the wait for + LDS writes of the next stage's activation batch.
   auto kstep_block = [&](auto ks_c, auto land_c, const WFrag& cur, const BStep& nxt, const u32x2& s2, WFrag& out,
-                         u32x4 (&af)[MT + 4], int buf, int st, BStep& refill) {
+                         u32x4 (&af)[MT + 4], int buf, int st, BStep& refill, const u32x2& z2 = u32x2{0, 0}) {
     constexpr int KS = decltype(ks_c)::value;
     constexpr bool LAND = decltype(land_c)::value;
     const char* rb = (KS == 0 ? r_base0 : r_base1) + buf * A_IMG;
     const char* rb1 = r_base1 + buf * A_IMG;
     uint32_t tmp[2];
-    if constexpr (!FAST) dequant_cxx(nxt, s2, out);
+    if constexpr (!FAST) dequant_cxx(nxt, s2, out, z2);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       u32x4 wq[NTILE];
@@ -424,7 +454,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   };
   // FAST path: the same block with the conversion operations placed two per MFMA
   auto kstep_block_fast = [&](auto ks_c, auto land_c, const WFrag& cur, const BStep& nxt, const u32x2& s2, WFrag& out,
-                              u32x4 (&af)[MT + 4], int buf, int st, BStep& refill) {
+                              u32x4 (&af)[MT + 4], int buf, int st, BStep& refill, const u32x2& z2 = u32x2{0, 0}) {
     constexpr int KS = decltype(ks_c)::value;
     constexpr bool LAND = decltype(land_c)::value;
     const char* rb = (KS == 0 ? r_base0 : r_base1) + buf * A_IMG;
@@ -435,14 +465,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     for (int t = 0; t < NTILE; ++t) wq[t] = u32x4{cur.w[t][0], cur.w[t][1], cur.w[t][2], cur.w[t][3]};
     constexpr int NOPS = DqPlan<SCALED>::TOTAL;
     constexpr int OPM = (NOPS + MT * NTILE - 1) / (MT * NTILE);  // conversion operations per MFMA: 2 (MT = 8) / 3-4 (MT = 4)
+    u32x2 zh2 = {0, 0};
+    if constexpr (ZP) {
+      zh2[0] = h2_bits(bits_h2(z2[0]) + bits_h2(0x63806380u));
+      zh2[1] = h2_bits(bits_h2(z2[1]) + bits_h2(0x63806380u));
+    }
     auto ops = [&](auto i_c) {  // the conversion operations behind MFMA number i
       constexpr int I = decltype(i_c)::value;
       if constexpr ((NMX_WABLATE & 2) == 0) {
         if constexpr (I4) {
-          if constexpr (OPM * I < NOPS) dq_op<SCALED, OPM * I>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
-          if constexpr (OPM * I + 1 < NOPS) dq_op<SCALED, OPM * I + 1>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
-          if constexpr (OPM > 2 && OPM * I + 2 < NOPS) dq_op<SCALED, OPM * I + 2>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
-          if constexpr (OPM > 3 && OPM * I + 3 < NOPS) dq_op<SCALED, OPM * I + 3>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72);
+          if constexpr (OPM * I < NOPS) dq_op<SCALED, OPM * I, ZP>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72, z2, zh2);
+          if constexpr (OPM * I + 1 < NOPS) dq_op<SCALED, OPM * I + 1, ZP>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72, z2, zh2);
+          if constexpr (OPM > 2 && OPM * I + 2 < NOPS) dq_op<SCALED, OPM * I + 2, ZP>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72, z2, zh2);
+          if constexpr (OPM > 3 && OPM * I + 3 < NOPS) dq_op<SCALED, OPM * I + 3, ZP>(nxt.q0, nxt.q1, s2, out, tmp, magic, neg72, z2, zh2);
         }
       }
     };
@@ -524,6 +559,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 
   // ---- prologue, in the steady-state issue order ----
   if constexpr (SCALED) scc = __builtin_amdgcn_raw_buffer_load_b64(rs_s, s_voff, scale_soff(stage_of(0)), 0);
+  if constexpr (ZP) zcc = __builtin_amdgcn_raw_buffer_load_b64(rs_z, s_voff, scale_soff(stage_of(0)), 0);
   issue_w(stage_of(0), 0, ring[0]);
   issue_batch(0);
 #pragma unroll
@@ -531,10 +567,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 #pragma unroll
   for (int i = 0; i < NA; ++i) write_piece(i, 0);
   scn = sraw;
+  zcn = zraw;
   if constexpr (SP) {
     dequant_sp64(ring[0], ring[1], scc, sfa);
     issue_w(stage_of((RD + 1) >> 1), 1, ring[1]);  // slot 1 is free again: k-step RD + 1
-  } else dequant_cxx(ring[0], scc, wfa);
+  } else dequant_cxx(ring[0], scc, wfa, zcc);
   // the same order as an iteration issues them: hipcc merges the pending-load state of this path and of the loop's back
   // edge at the loop head, and any difference turns the first waits of the body into vmcnt(0)
   issue_w(stage_of((RD - 1) >> 1), 1, ring[RD - 1]);
@@ -573,18 +610,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
       for (int mt = 0; mt < MT + 4; ++mt) af[mt] = u32x4{(uint32_t)lane, (uint32_t)it, (uint32_t)mt, 0x3c003c00u};
     }
     if constexpr (FAST) {
-      kstep_block_fast(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR, st, r1);
-      kstep_block_fast(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af, PAR, st, r1);
+      kstep_block_fast(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR, st, r1, zcc);
+      kstep_block_fast(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af, PAR, st, r1, zcn);
     } else {
-      kstep_block(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR, st, r1);
+      kstep_block(KS0{}, NOLAND{}, wfa, r1, scc, wfb, af, PAR, st, r1, zcc);
       // k-step 1 of the generic path reads its fragments 4..7 into af[4..7] and 0..3 from af[8..11]
       u32x4 af1[MT + 4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) af1[mt] = af[MT + mt];
-      kstep_block(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af1, PAR, st, r1);
+      kstep_block(KS1{}, DOLAND{}, wfb, r2, scn, wfa, af1, PAR, st, r1, zcn);
     }
     scc = scn;
     scn = sraw;
+    zcc = zcn;
+    zcn = zraw;
     load_scale(wpos[1]);               // scale row of walk position st + 3
     issue_w(wpos[NCUR - 1], 0, r2);    // k-step 2 st + 2 + RD
     walk_advance(st);
@@ -731,7 +770,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
   }
 }
 
-template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MT = 8, bool SP = false>
+template <typename scalar_t, int KIND, int MODE, int WM, int WN, int WK, int MT = 8, bool SP = false, bool ZP = false>
 int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = 16 * MT * WM;
   const size_t stage = (size_t)WK * 2 * BM * 128;
@@ -739,7 +778,7 @@ int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
   const size_t ex = (size_t)WM * (WN / 2) * MT * 4 * 64 * 8;  // fused silu_and_mul: the up halves as fp16 / bf16
   const size_t smem = std::max(std::max(stage, red), ex);
   dim3 grid(ceil_div(ceil_div(p.N, 64 * WN), 8) * 8 * ceil_div(p.M, BM), p.k_splits, 1);
-  auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK, MT, SP>;
+  auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK, MT, SP, ZP>;
   if (smem > 64 * 1024)
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   kern<<<grid, 64 * WM * WN * WK, smem, stream>>>(p);
@@ -780,6 +819,13 @@ int launch_wide_sparse(const GemmParams& p, const NmxWideCfg& c, hipStream_t str
   }
   if (c.wn == 2) return launch_wide_cfg<f16, KIND, 0, 1, 2, 4, 8, true>(p, stream);
   return launch_wide_cfg<f16, KIND, 0, 1, 4, 2, 8, true>(p, stream);
+}
+
+// zero-point launches (AWQ on the Marlin layout): fp16 int4, grouped; 128-row wave tiles as 1 x 4 x 2 or 1 x 2 x 4 waves
+int launch_wide_zp(const GemmParams& p, const NmxWideCfg& c, hipStream_t stream) {
+  // 128-row wave tiles as 1 x 4 x 2 waves only: 1 x 2 x 4 spills 12 registers with the zero rows on top, and the 64-row wave
+  // tiles measured level with / behind the row-block kernel on the 70B / TP = 8 shapes (o 13.2 vs 13.9 us, down 26.9 vs 25.0)
+  return launch_wide_cfg<f16, W_INT4, 1, 1, 4, 2, 8, false, true>(p, stream);
 }
 
 template <typename scalar_t, int KIND>
@@ -880,14 +926,14 @@ bool nmx_wide_pick(int M, int N, int K, int num_groups, int group_size, NmxWideC
 
 int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream) {
   GemmParams p;
-  p.a = call.a; p.b = call.b; p.meta = call.meta; p.zeros = nullptr; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
+  p.a = call.a; p.b = call.b; p.meta = call.meta; p.zeros = call.zeros; p.scales = call.scales; p.g_idx = nullptr; p.perm = nullptr; p.c = call.c;
   p.M = call.M; p.N = call.N; p.K = call.K; p.num_groups = call.num_groups; p.group_size = call.group_size;
   p.slow_act_order = 0;
   if (const char* e = nmx_tune(NMX_TUNE_GEMM_XCD_SPLIT)) p.xcd_split = atoi(e) != 0;
   p.defer_reduce = call.defer_reduce;
   p.k_splits = cfg.splits;
   // fused silu_and_mul epilogue: only a launch whose workgroups own whole K (the slabs of a K split belong to the consumer)
-  call.act_done = (call.meta == nullptr && call.act_out != nullptr && cfg.splits == 1 && call.N % 2 == 0 && (call.N / 2) % (64 * cfg.wn) == 0) ? 1 : 0;
+  call.act_done = (call.meta == nullptr && call.zeros == nullptr && call.act_out != nullptr && cfg.splits == 1 && call.N % 2 == 0 && (call.N / 2) % (64 * cfg.wn) == 0) ? 1 : 0;
   p.act_out = call.act_done ? call.act_out : nullptr;
   if (p.k_splits > 1) {  // never allocate here (graph capture): degrade to the splits that fit
     const int64_t per = (int64_t)p.M * p.N * sizeof(float);
@@ -899,7 +945,11 @@ int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream
 #ifdef NMX_WIDE_MIN  // experiment builds: fp16 int4 only (compile time)
   rc = launch_wide_kind<f16, W_INT4>(p, cfg, stream);
 #else
-  if (call.meta != nullptr) {
+  if (call.zeros != nullptr) {
+    if (call.is_bf16 || call.kind != W_INT4 || call.num_groups <= 1 || cfg.wm != 1 || !(cfg.mt == 8 && cfg.wn == 4))
+      return NMX_ERR_UNSUPPORTED;
+    rc = launch_wide_zp(p, cfg, stream);
+  } else if (call.meta != nullptr) {
     if (call.is_bf16 || call.kind == W_FP8) return NMX_ERR_UNSUPPORTED;
     rc = call.kind == W_INT4 ? launch_wide_sparse<W_INT4>(p, cfg, stream) : launch_wide_sparse<W_INT8>(p, cfg, stream);
   } else

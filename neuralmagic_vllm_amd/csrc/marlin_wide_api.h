@@ -20,6 +20,7 @@ struct NmxWideCall {
   void* act_out = nullptr;  // [M, N / 2]: fuse silu_and_mul into the epilogue when the launch has no K split (see act_done)
   int act_done = 0;         // out: act_out was written (and c was not)
   const void* meta = nullptr;  // 2:4-sparse weights (gptq_marlin_24_gemm): the reordered metadata tensor; b is then the compressed tensor
+  const void* zeros = nullptr; // AWQ on the Marlin layout (awq_marlin_gemm): [num_groups, N] fp16 -(1024 + z), permuted like the scales
 };
 
 // tile configuration of marlin_wide_kernel: wm x wn x wk waves, `splits` K splits across workgroups

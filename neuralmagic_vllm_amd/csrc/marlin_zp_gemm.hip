@@ -9,6 +9,7 @@
 // w = (q - z) * s exactly as awq/dequantize.cuh:17-98: (1024 + q) - (1024 + z) is exact in fp16, then one rounding by s.
 // The op awq_gemm itself (checkpoint layout in, vllm._custom_ops surface) is unchanged.
 #include "marlin_kernel.h"
+#include "marlin_wide_api.h"
 
 namespace {
 
@@ -92,6 +93,20 @@ static int awq_marlin_common(const void* a, const int32_t* q, const void* scales
   p.a = a; p.b = q; p.meta = nullptr; p.scales = scales; p.zeros = zeros; p.g_idx = nullptr; p.perm = nullptr; p.c = c;
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.group_size = size_k / num_groups;
   p.slow_act_order = 0; p.defer_reduce = defer ? 1 : 0;
+  // M > 64: the wide 128 x 256 tiles (marlin_wide_kernel<ZP>, round 3) where the dense dispatch takes them (70B / TP = 8 gate_up at
+  // M = 256: 40.3 vs 42.9 us)
+  NmxWideCfg wc;
+  if (nmx_wide_pick(size_m, size_n, size_k, num_groups, p.group_size, &wc, W_INT4) && wc.wm == 1 && size_m > 64 &&
+      wc.mt == 8 && wc.wn == 4) {
+    NmxWideCall call;
+    call.a = a; call.b = q; call.scales = scales; call.c = c; call.scratch = scratch; call.scratch_bytes = scratch_bytes;
+    call.M = size_m; call.N = size_n; call.K = size_k; call.num_groups = num_groups; call.group_size = p.group_size;
+    call.kind = W_INT4; call.is_bf16 = 0; call.defer_reduce = defer ? 1 : 0;
+    call.zeros = zeros;
+    const int rc = nmx_wide_launch(call, wc, stream);
+    if (rc == NMX_OK && splits_out != nullptr) *splits_out = call.splits_done;
+    return rc;
+  }
   GemmCfg cfg = pick_cfg(size_m, size_n, size_k);
   // the 64-row x 128-column tiles need more registers than two waves per SIMD leave with the zero points on top (hipcc
   // spills, and a spill of a register an in-flight load is writing is not safe): 256-column tiles instead

@@ -253,6 +253,29 @@ def test_awq_marlin_path(ops, m, k, n):
     assert torch.equal(mq.cpu(), packing.marlin_weights(codes, k, n, 4))
 
 
+@pytest.mark.parametrize("wide", ["1,4,1", "1,4,2", "1,4,4", "0", None])
+@pytest.mark.parametrize("m,k,n", [(65, 512, 512), (128, 1024, 256), (200, 2048, 384), (256, 8192, 7168), (300, 3584, 1024)])
+def test_awq_marlin_wide_kernel(ops, tune, m, k, n, wide):
+    """Round 3: marlin_wide_kernel<ZP> (AWQ weights on the wide tiles, M > 64: the hand-placed conversion plan with its two
+    fix-up constants taken from the zero row) on its 128 x 256 tiles, with K splits, ragged rows, padding column groups,
+    and the 70B / TP = 8 gate_up shape - against a @ w_ref, and against the row-block kernel (NMX_GEMM_WIDE=0)."""
+    if wide not in (None, "0") and (k, n) == (8192, 7168) and wide != "1,4,4":
+        pytest.skip("large shape covered with one forced configuration")
+    seed_all(m + k)
+    w = torch.randn(k, n)
+    a = torch.randn(m, k, dtype=torch.float16)
+    w_ref, qweight, qzeros, scales = packing.awq_quantize(w, 128)
+    mq, ms, mz = ops.awq_marlin_repack(qweight.to(DEV), qzeros.to(DEV), scales.to(DEV))
+    tune(NMX_GEMM_WIDE=wide)
+    out = ops.awq_marlin_gemm(a.to(DEV), mq, ms, mz, m, n, k)
+    assert compute_max_diff(out.float().cpu(), a.float() @ w_ref.float()) < TOL
+    d = ops.awq_marlin_gemm_deferred(a.to(DEV), mq, ms, mz, m, n, k)
+    assert torch.equal(d.materialize().view(torch.int16), out.view(torch.int16))
+    tune(NMX_GEMM_WIDE="0")
+    base = ops.awq_marlin_gemm(a.to(DEV), mq, ms, mz, m, n, k)
+    assert compute_max_diff(out.float().cpu(), base.float().cpu()) < TOL
+
+
 def test_awq_layer_uses_marlin_path(ops):
     from neuralmagic_vllm_amd.layers.linear import ColumnParallelLinear
     from neuralmagic_vllm_amd.layers.quantization.awq import AWQConfig

@@ -14,6 +14,8 @@ import torch  # noqa: E402
 from neuralmagic_vllm_amd import _custom_ops as ops  # noqa: E402
 
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+if os.environ.get("LEAN_SWEEP_SET") == "70b-tp8":  # one rank of Llama-3-70B at TP = 8 (bench.py LLAMA3_70B_TP8_RANK)
+    SHAPES = {"qkv": (8192, 1280), "o": (1024, 8192), "gate_up": (8192, 7168), "down": (3584, 8192)}
 NL = 32
 dev = "cuda:0"
 
@@ -93,7 +95,7 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(0)
     e = torch.empty(0, dtype=torch.int32, device=dev)
-    wsp = torch.zeros(28672 // 64 * 16, dtype=torch.int32, device=dev)
+    wsp = torch.zeros(28672 // 64 * 16, dtype=torch.int32, device=dev)  # (>= N / 64 * 16 for every shape set)
     only_shapes = os.environ.get("LEAN_SWEEP_SHAPES")
     for name, (K, N) in SHAPES.items():
         if only_shapes and name not in only_shapes.split(","):
