@@ -396,3 +396,46 @@ def test_random_add_rms_norm_consumer(ops, M, N, K):
     fused = ops.fused_add_rms_norm_splitk(d, res_b, w, 1e-5)
     torch.cuda.synchronize()
     assert torch.equal(fused.view(torch.int16), plain.view(torch.int16)) and torch.equal(res_a.view(torch.int16), res_b.view(torch.int16))
+
+
+# ---- gptq_marlin_24_gemm (2:4-sparse): row-block kernel (M <= 32 and the shapes the wide rules leave) and marlin_wide_kernel<SP> ----
+def _sparse_case(rng):
+    M = rng.choice([1, 5, 16, 17, 32, 33, 48, 64, 65, 96, 128, 129, 200, 256, 257, 300])
+    N = 128 * rng.choice([1, 2, 3, 8, 12, 16, 33, 48, 56, 64, 112, 224])
+    K = 128 * rng.choice([1, 2, 3, 4, 7, 8, 16, 28, 32, 33, 56])
+    return M, N, K, rng.choice([-1, 128]), rng.choice([4, 4, 8])
+
+
+SPARSE_CASES = []
+_srng = random.Random(20243)
+while len(SPARSE_CASES) < 40:
+    c = _sparse_case(_srng)
+    if c not in SPARSE_CASES:
+        SPARSE_CASES.append(c)
+
+
+@pytest.mark.parametrize("M,N,K,group,bits", SPARSE_CASES)
+def test_random_shape_sparse24(ops, tune, M, N, K, group, bits):
+    """Default dispatch of gptq_marlin_24_gemm on random compressed words + random VALID metadata against the CPU oracle on the
+    first and last 128 columns (1e-3), against the row-block kernel on the whole output, and its deferred form bit for bit."""
+    gen = torch.Generator().manual_seed(M + N + K + bits)
+    pack = 32 // bits
+    mq = torch.randint(-2**31, 2**31 - 1, (K // 32, N * 16 // pack), dtype=torch.int32, generator=gen)
+    nib = torch.tensor([0x4, 0x8, 0xC, 0x9, 0xD, 0xE], dtype=torch.int32)  # (idx0 | idx1 << 2), idx0 < idx1
+    pick = nib[torch.randint(0, 6, (K // 32, N * 2, 4), generator=gen)]
+    meta = (pick[..., 0] | (pick[..., 1] << 4) | (pick[..., 2] << 8) | (pick[..., 3] << 12)).to(torch.int16)
+    groups = 1 if group == -1 else K // group
+    ms = (torch.rand(groups, N, generator=gen) * 0.01 + 0.005).to(torch.float16)
+    a = torch.randn(M, K, dtype=torch.float16, generator=gen)
+    ws = torch.zeros(N // 128 * 64, dtype=torch.int32, device=DEV)
+    ad, qd, md, sd = a.to(DEV), mq.to(DEV), meta.to(DEV), ms.to(DEV)
+    c = ops.gptq_marlin_24_gemm(ad, qd, md, sd, ws, bits, M, N, K)
+    for lo in sorted({0, N - 128}):
+        orc = oracle.gptq_marlin_24_gemm(a, mq[:, lo * 16 // pack:(lo + 128) * 16 // pack].contiguous(), meta[:, lo * 2:(lo + 128) * 2].contiguous(),
+                                         ms[:, lo:lo + 128].contiguous(), None, bits, M, 128, K)
+        assert compute_max_diff(c[:, lo:lo + 128].float().cpu(), orc) < 1e-3, (M, N, K, group, bits, lo)
+    d = ops.gptq_marlin_24_gemm_deferred(ad, qd, md, sd, ws, bits, M, N, K)
+    assert torch.equal(d.materialize().view(torch.int16), c.view(torch.int16))
+    tune(NMX_GEMM_WIDE="0")
+    base = ops.gptq_marlin_24_gemm(ad, qd, md, sd, ws, bits, M, N, K)
+    assert compute_max_diff(c.float().cpu(), base.float().cpu()) < 1e-3
