@@ -1,6 +1,8 @@
 """GPU parity tests for the Marlin family (gptq_marlin_repack bit-exact; gptq_marlin_gemm / marlin_gemm /
 fp8_marlin_gemm vs the CPU oracle). Mirrors tests/kernels/test_marlin_gemm.py of the reference: same shape grid,
 its bar is mean|d|/mean|ref| < 0.04; ours is <= 1e-3 (north-star), against a.float() @ w_ref.float()."""
+import functools
+
 import numpy as np
 import pytest
 import torch
@@ -68,13 +70,24 @@ def test_marlin_repack(ops, k_chunk, n_chunk, num_bits, group_size, act_order, m
     assert torch.equal(got.cpu(), expect)
 
 
+@functools.lru_cache(maxsize=4)
+def _quantized_case(size_m, size_k, size_n, num_bits, group_size, act_order):
+    """Seeded inputs + the reference quantizer's output (CPU, the slow part of the grid test): the is_k_full = False / True
+    cases of one shape run back to back and share it."""
+    seed_all(0)
+    a = torch.randn(size_m, size_k, dtype=torch.float16)
+    w = torch.randn(size_k, size_n, dtype=torch.float16)
+    w_ref, mq, ms, g_idx, sort_idx, _ = packing.marlin_quantize(w, num_bits, group_size, act_order)
+    return a, w_ref, mq, ms, g_idx, sort_idx
+
+
+@pytest.mark.parametrize("is_k_full", [False, True])
 @pytest.mark.parametrize("k_chunk", MARLIN_K_CHUNKS)
 @pytest.mark.parametrize("n_chunk", MARLIN_N_CHUNKS)
 @pytest.mark.parametrize("num_bits", NUM_BITS)
 @pytest.mark.parametrize("group_size", GROUP_SIZES)
 @pytest.mark.parametrize("mnk_factors", MNK_FACTORS)
 @pytest.mark.parametrize("act_order", [False, True])
-@pytest.mark.parametrize("is_k_full", [False, True])
 def test_marlin_gemm(ops, k_chunk, n_chunk, num_bits, group_size, mnk_factors, act_order, is_k_full):
     """tests/kernels/test_marlin_gemm.py:126-179"""
     m_factor, n_factor, k_factor = mnk_factors
@@ -83,10 +96,7 @@ def test_marlin_gemm(ops, k_chunk, n_chunk, num_bits, group_size, mnk_factors, a
         pytest.skip("act_order needs groups")
     if not act_order and not is_k_full:
         pytest.skip("is_k_full only matters with act_order")
-    seed_all(0)
-    a = torch.randn(size_m, size_k, dtype=torch.float16)
-    w = torch.randn(size_k, size_n, dtype=torch.float16)
-    w_ref, mq, ms, g_idx, sort_idx, _ = packing.marlin_quantize(w, num_bits, group_size, act_order)
+    a, w_ref, mq, ms, g_idx, sort_idx = _quantized_case(size_m, size_k, size_n, num_bits, group_size, act_order)
     out = ops.gptq_marlin_gemm(a.to(DEV), mq.to(DEV), ms.to(DEV), g_idx.to(DEV), sort_idx.to(DEV), workspace(size_n),
                                num_bits, size_m, size_n, size_k, is_k_full)
     ref = torch.matmul(a.float(), w_ref.float())
