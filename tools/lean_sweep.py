@@ -14,6 +14,8 @@ import torch  # noqa: E402
 from neuralmagic_vllm_amd import _custom_ops as ops  # noqa: E402
 
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+if os.environ.get("LEAN_SWEEP_SET") == "kscan":  # gate_up's N at growing K: time = fixed cost of a launch + stages x cost of a stage
+    SHAPES = {f"k{k}": (k, 28672) for k in (256, 512, 1024, 2048, 4096)}
 if os.environ.get("LEAN_SWEEP_SET") == "70b-tp8":  # one rank of Llama-3-70B at TP = 8 (bench.py LLAMA3_70B_TP8_RANK)
     SHAPES = {"qkv": (8192, 1280), "o": (1024, 8192), "gate_up": (8192, 7168), "down": (3584, 8192)}
 NL = 32
