@@ -176,6 +176,12 @@ int nmx_gptq_marlin_gemm_deferred(const void* a, const int32_t* b_q_weight, cons
                                   const int32_t* perm, void* c, int64_t workspace_numel, void* scratch,
                                   int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits,
                                   int num_groups, int is_k_full, int dtype, int* splits_out, nmx_stream_t stream);
+/* `splits` of the split-K consumers below and of nmx_splitk_reduce: bits 0..7 = number of slabs; NMX_SPLITK_F16 set = the slabs
+ * hold fp16 instead of fp32 partial sums. The *_deferred GEMM entries report the value to pass on in *splits_out (the M > 64
+ * Marlin kernels write fp16 slabs for fp16 outputs since round 3: half the slab traffic; the reference's own global reduce hands
+ * fp16 partials from block to block, gptq_marlin.cu). */
+#define NMX_SPLITK_F16 0x100
+
 /* out [size_m, size_n] = scalar_t(sum_s partial[s]), s = 0, 1, ... : the split-K reduce launch as an op, for consumers of a
  * deferred GEMM without a fused form (same bits as the plain GEMM's output). */
 int nmx_splitk_reduce(void* out, const float* partial, int splits, int size_m, int size_n, int dtype, nmx_stream_t stream);

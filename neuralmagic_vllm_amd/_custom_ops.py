@@ -517,25 +517,43 @@ def marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tenso
 # fused decode path (extensions, not part of vllm._custom_ops): the split-K reduction of a Marlin GEMM is deferred to the
 # op that consumes its output. Every combination is bit-identical to the plain op sequence; the plain ops stay available.
 # ---------------------------------------------------------------------------------------------------------
+_SPLITK_F16 = 0x100  # NMX_SPLITK_F16 (include/nmx.h): the slabs hold fp16 partial sums
+
+
+def _slabs(scratch: torch.Tensor, coded: int, size_m: int, size_n: int):
+    """(partial view, slab count) of what a *_deferred entry reported in *splits_out (count | NMX_SPLITK_F16)."""
+    n = coded & 0xff
+    if coded & _SPLITK_F16:
+        return scratch[:n * size_m * size_n * 2].view(torch.float16).view(n, size_m, size_n), n
+    return scratch[:n * size_m * size_n * 4].view(torch.float32).view(n, size_m, size_n), n
+
+
 class DeferredGemm:
-    """Output of gptq_marlin_gemm_deferred: `out` [M, N] (valid iff splits == 1), else `partial` [splits, M, N] fp32."""
+    """Output of gptq_marlin_gemm_deferred: `out` [M, N] (valid iff splits == 1), else `partial` [splits, M, N] - fp32, or fp16
+    from the M > 64 Marlin kernels (round 3: half the slab traffic; the consumers and the reduce entry take the dtype with the
+    count, see `coded`)."""
     __slots__ = ("out", "partial", "splits", "sa", "sb")
 
     def __init__(self, out, partial, splits, sa=None, sb=None):
         self.out, self.partial, self.splits = out, partial, splits
         self.sa, self.sb = sa, sb  # per-tensor scales of a deferred fp8 scaled_mm (applied by the consumer), else None
 
+    @property
+    def coded(self) -> int:
+        """The `splits` argument of the C-ABI consumers: slab count | NMX_SPLITK_F16 for fp16 slabs."""
+        return self.splits | (_SPLITK_F16 if self.partial is not None and self.partial.dtype == torch.float16 else 0)
+
     def materialize(self) -> torch.Tensor:
         """Plain reduction (what the reduce launch would have produced), for consumers without a fused form."""
         if self.splits > 1:
             if self.sa is not None:  # fp8 scaled_mm: the scale epilogue belongs to the reduction (the GEMM's own reduce kernel)
                 m, n = self.out.shape
-                _lib.check(_lib.lib().nmx_splitk_reduce_scaled(_p(self.out), _p(self.partial), c_int(self.splits), _p(self.sa),
+                _lib.check(_lib.lib().nmx_splitk_reduce_scaled(_p(self.out), _p(self.partial), c_int(self.coded), _p(self.sa),
                                                                _p(self.sb), c_int(m), c_int(n), c_i64(self.out.stride(0)),
                                                                c_int(_dt(self.out)), _stream(self.out)))
             else:  # the GEMMs' own reduce kernel: slabs summed in the order s = 0, 1, ... like the plain op
                 m, n = self.out.shape
-                _lib.check(_lib.lib().nmx_splitk_reduce(_p(self.out), _p(self.partial), c_int(self.splits), c_int(m), c_int(n),
+                _lib.check(_lib.lib().nmx_splitk_reduce(_p(self.out), _p(self.partial), c_int(self.coded), c_int(m), c_int(n),
                                                         c_int(_dt(self.out)), _stream(self.out)))
             self.splits = 1
         return self.out
@@ -559,9 +577,9 @@ def gptq_marlin_gemm_deferred(a: torch.Tensor, b_q_weight: torch.Tensor, b_scale
         _p(a), _p(b_q_weight), _p(b_scales), _p(g_idx if has_idx else None), _p(perm if has_idx else None), _p(c),
         c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n), c_int(size_k),
         c_int(num_bits), c_int(b_scales.shape[0]), c_int(int(is_k_full)), c_int(_dt(a)), ctypes.byref(splits), _stream(a)))
-    if splits.value > 1:
-        partial = scratch[:splits.value * size_m * size_n * 4].view(torch.float32).view(splits.value, size_m, size_n)
-        return DeferredGemm(c, partial, splits.value)
+    if (splits.value & 0xff) > 1:
+        partial, n = _slabs(scratch, splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, n)
     return DeferredGemm(c, None, 1)
 
 
@@ -604,10 +622,10 @@ def fused_add_rms_norm_splitk(g: DeferredGemm, residual: torch.Tensor, weight: t
     amax = torch.empty(out.shape[0], dtype=torch.float32, device=out.device) if want_absmax else None
     if g.sa is not None or want_absmax:
         _lib.check(_lib.lib().nmx_fused_add_rms_norm_splitk_scaled(
-            _p(out), _p(g.partial), c_int(g.splits), _p(g.sa), _p(g.sb), _p(residual), _p(weight), c_f(epsilon),
+            _p(out), _p(g.partial), c_int(g.coded), _p(g.sa), _p(g.sb), _p(residual), _p(weight), c_f(epsilon),
             c_int(out.shape[0]), c_int(out.shape[1]), c_int(_dt(out)), _p(amax), _stream(out)))
     else:
-        _lib.check(_lib.lib().nmx_fused_add_rms_norm_splitk(_p(out), _p(g.partial), c_int(g.splits), _p(residual), _p(weight),
+        _lib.check(_lib.lib().nmx_fused_add_rms_norm_splitk(_p(out), _p(g.partial), c_int(g.coded), _p(residual), _p(weight),
                                                             c_f(epsilon), c_int(out.shape[0]), c_int(out.shape[1]),
                                                             c_int(_dt(out)), _stream(out)))
     g.splits = 1
@@ -624,10 +642,10 @@ def silu_and_mul_splitk(out: torch.Tensor, g: DeferredGemm, want_absmax: bool = 
     T, d = out.shape
     amax = torch.empty(T, dtype=torch.float32, device=out.device) if want_absmax else None
     if g.sa is not None or want_absmax:
-        _lib.check(_lib.lib().nmx_silu_and_mul_splitk_scaled(_p(out), _p(g.partial), c_int(g.splits), _p(g.sa), _p(g.sb), c_int(T),
+        _lib.check(_lib.lib().nmx_silu_and_mul_splitk_scaled(_p(out), _p(g.partial), c_int(g.coded), _p(g.sa), _p(g.sb), c_int(T),
                                                              c_int(d), c_int(_dt(out)), _p(amax), _stream(out)))
     else:
-        _lib.check(_lib.lib().nmx_silu_and_mul_splitk(_p(out), _p(g.partial), c_int(g.splits), c_int(T), c_int(d), c_int(_dt(out)),
+        _lib.check(_lib.lib().nmx_silu_and_mul_splitk(_p(out), _p(g.partial), c_int(g.coded), c_int(T), c_int(d), c_int(_dt(out)),
                                                       _stream(out)))
     return amax
 
@@ -647,13 +665,13 @@ def rope_reshape_and_cache(positions: torch.Tensor, g, num_heads: int, num_kv_he
     block_size = value_cache.shape[3]
     if g.splits > 1 and g.sa is not None:
         _lib.check(_lib.lib().nmx_rope_reshape_and_cache_scaled(
-            _p(positions), _p(qkv), _p(g.partial), c_int(g.splits), _p(g.sa), _p(g.sb), _p(cos_sin_cache), _p(key_cache),
+            _p(positions), _p(qkv), _p(g.partial), c_int(g.coded), _p(g.sa), _p(g.sb), _p(cos_sin_cache), _p(key_cache),
             _p(value_cache), _p(slot_mapping), c_int(qkv.shape[0]), c_int(num_heads), c_int(num_kv_heads), c_int(head_size),
             c_int(block_size), c_int(_dt(qkv)), c_int(_kv(kv_cache_dtype)), c_f(kv_scale), _stream(qkv)))
         g.splits = 1
         return qkv
     _lib.check(_lib.lib().nmx_rope_reshape_and_cache(
-        _p(positions), _p(qkv), _p(g.partial), c_int(g.splits), _p(cos_sin_cache), _p(key_cache), _p(value_cache),
+        _p(positions), _p(qkv), _p(g.partial), c_int(g.coded), _p(cos_sin_cache), _p(key_cache), _p(value_cache),
         _p(slot_mapping), c_int(qkv.shape[0]), c_int(num_heads), c_int(num_kv_heads), c_int(head_size), c_int(block_size),
         c_int(_dt(qkv)), c_int(_kv(kv_cache_dtype)), c_f(kv_scale), _stream(qkv)))
     g.splits = 1
@@ -721,9 +739,9 @@ def gptq_marlin_24_gemm_deferred(a: torch.Tensor, b_q_weight: torch.Tensor, b_me
                                                            c_int(num_bits), c_int(size_m), c_int(size_n), c_int(size_k),
                                                            c_int(b_scales.size(0)), c_int(_dt(a)), ctypes.byref(splits),
                                                            _stream(a)))
-    if splits.value > 1:
-        partial = scratch[:splits.value * size_m * size_n * 4].view(torch.float32).view(splits.value, size_m, size_n)
-        return DeferredGemm(c, partial, splits.value)
+    if (splits.value & 0xff) > 1:
+        partial, n = _slabs(scratch, splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, n)
     return DeferredGemm(c, None, 1)
 
 
@@ -858,9 +876,9 @@ def awq_marlin_gemm_deferred(a: torch.Tensor, marlin_q: torch.Tensor, marlin_sca
                                                        _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n),
                                                        c_int(size_k), c_int(marlin_scales.shape[0]), ctypes.byref(splits),
                                                        _stream(a)))
-    if splits.value > 1:
-        partial = scratch[:splits.value * size_m * size_n * 4].view(torch.float32).view(splits.value, size_m, size_n)
-        return DeferredGemm(c, partial, splits.value)
+    if (splits.value & 0xff) > 1:
+        partial, n = _slabs(scratch, splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, n)
     return DeferredGemm(c, None, 1)
 
 

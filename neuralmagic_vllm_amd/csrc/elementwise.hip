@@ -315,9 +315,23 @@ template <typename T>
 __device__ __forceinline__ void sum_partials8(const float* __restrict__ partial, int splits, int64_t slab, int64_t off, T (&e)[8],
                                               const float* __restrict__ sa = nullptr, const float* __restrict__ sb = nullptr) {
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-  for (int sidx = 0; sidx < splits; ++sidx) {
-    a0 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off);
-    a1 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off + 4);
+  const int ns = NMX_SPLITK_COUNT(splits);
+  if (splits & NMX_SPLITK_F16) {  // (uniform) fp16 slabs: 16 bytes = the 8 elements
+    const f16* ph = reinterpret_cast<const f16*>(partial);
+    for (int sidx = 0; sidx < ns; ++sidx) {
+      union { u32x4 u; f16 h[8]; } v;
+      v.u = *reinterpret_cast<const u32x4*>(ph + sidx * slab + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] += (float)v.h[j];
+        a1[j] += (float)v.h[4 + j];
+      }
+    }
+  } else {
+    for (int sidx = 0; sidx < ns; ++sidx) {
+      a0 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off);
+      a1 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off + 4);
+    }
   }
   if (sa != nullptr) {
     const float va = sa[0], vb = sb[0];
@@ -594,7 +608,7 @@ static int add_rms_norm_splitk_common(void* input_out, const float* partial, int
   if (num_tokens == 0) return NMX_OK;
   NMX_CHECK((sa == nullptr) == (sb == nullptr), NMX_ERR_INVALID_ARG, "splitk consumer: both scales or neither");
   NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "fused_add_rms_norm_splitk: fp16 / bf16 only");
-  NMX_CHECK(splits >= 2 && partial != nullptr, NMX_ERR_INVALID_ARG, "fused_add_rms_norm_splitk needs >= 2 partial slabs");
+  NMX_CHECK(NMX_SPLITK_COUNT(splits) >= 2 && partial != nullptr, NMX_ERR_INVALID_ARG, "fused_add_rms_norm_splitk needs >= 2 partial slabs");
   NMX_CHECK(hidden_size % 8 == 0 && hidden_size / 8 <= 2048 &&
                 (((uintptr_t)input_out | (uintptr_t)partial | (uintptr_t)residual | (uintptr_t)weight) % 16 == 0),
             NMX_ERR_INVALID_ARG, "fused_add_rms_norm_splitk: hidden %% 8 == 0 (<= 16384) and 16-byte aligned operands");
@@ -633,7 +647,7 @@ static int silu_and_mul_splitk_common(void* out, const float* partial, int split
   if (num_tokens == 0 || d == 0) return NMX_OK;
   NMX_CHECK((sa == nullptr) == (sb == nullptr), NMX_ERR_INVALID_ARG, "splitk consumer: both scales or neither");
   NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "silu_and_mul_splitk: fp16 / bf16 only");
-  NMX_CHECK(splits >= 2 && partial != nullptr && d % 8 == 0 && (((uintptr_t)out | (uintptr_t)partial) % 16 == 0),
+  NMX_CHECK(NMX_SPLITK_COUNT(splits) >= 2 && partial != nullptr && d % 8 == 0 && (((uintptr_t)out | (uintptr_t)partial) % 16 == 0),
             NMX_ERR_INVALID_ARG, "silu_and_mul_splitk: >= 2 slabs, d %% 8 == 0, 16-byte aligned operands");
   const int threads = std::min(1024, std::max(64, ((d / 8 + 63) / 64) * 64));
   const int64_t slab = (int64_t)num_tokens * 2 * d;
@@ -662,7 +676,7 @@ static int rope_cache_common(const int64_t* positions, void* qkv, const float* p
   NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "rope_reshape_and_cache: fp16 / bf16 only");
   NMX_CHECK(head_size % 16 == 0 && num_heads > 0 && num_kv_heads > 0, NMX_ERR_INVALID_ARG,
             "rope_reshape_and_cache: head_size %% 16 == 0 (NeoX rotary over the whole head)");
-  NMX_CHECK((splits == 1) || (splits >= 2 && partial != nullptr), NMX_ERR_INVALID_ARG, "bad split count %d", splits);
+  NMX_CHECK((splits == 1) || (NMX_SPLITK_COUNT(splits) >= 2 && partial != nullptr), NMX_ERR_INVALID_ARG, "bad split count %d", splits);
   NMX_CHECK((((uintptr_t)qkv | (uintptr_t)partial | (uintptr_t)cos_sin_cache | (uintptr_t)key_cache) % 16 == 0), NMX_ERR_INVALID_ARG,
             "rope_reshape_and_cache: operands must be 16-byte aligned");
   const int heads = num_heads + 2 * num_kv_heads;

@@ -60,6 +60,7 @@ struct DmaParams {
   float* partial;
   void* act_out;
   int M, N, K, num_groups, group_size, k_splits, xcd_split;
+  int partial_f16;  // the K-split slabs hold fp16 (NMX_SPLITK_F16)
 };
 
 __device__ __forceinline__ void a_mfma_f16(f32x4& acc, const u32x4& a, const u32x4& b) {
@@ -491,6 +492,11 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
         *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.c) + (int64_t)m * N + n) = r.u;
+      } else if (p.partial_f16) {
+        union { f16 h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
+        *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.partial) + ((int64_t)split_id * M + m) * N + n) = r.u;
       } else {
         *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
       }
@@ -838,6 +844,11 @@ __global__ __launch_bounds__(512, 2) void marlin_pc_kernel(const DmaParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
         *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.c) + (int64_t)m * N + n) = r.u;
+      } else if (p.partial_f16) {
+        union { f16 h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
+        *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.partial) + ((int64_t)split_id * M + m) * N + n) = r.u;
       } else {
         *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
       }
@@ -854,6 +865,7 @@ static int nmx_dma_launch(NmxWideCall& call, int splits, int xcd_split, hipStrea
   p.a = call.a; p.b = call.b; p.scales = call.scales; p.c = call.c; p.partial = reinterpret_cast<float*>(call.scratch);
   p.M = call.M; p.N = call.N; p.K = call.K; p.num_groups = call.num_groups; p.group_size = call.group_size;
   p.k_splits = splits; p.xcd_split = xcd_split;
+  p.partial_f16 = (splits > 1 && nmx_tune(NMX_TUNE_SLAB_F32) == nullptr) ? 1 : 0;  // fp16 outputs only reach this kernel
   call.act_done = (call.act_out != nullptr && splits == 1 && call.N % 2 == 0 && (call.N / 2) % (64 * kWN) == 0) ? 1 : 0;
   p.act_out = call.act_done ? call.act_out : nullptr;
   const size_t ring = (size_t)kWK * kNBUF * kSlot;
@@ -876,7 +888,7 @@ static int nmx_dma_launch(NmxWideCall& call, int splits, int xcd_split, hipStrea
       kern<<<grid, 512, pc_smem, stream>>>(p);
     }
     NMX_LAUNCH_CHECK();
-    call.splits_done = splits;
+    call.splits_done = splits | (p.partial_f16 ? NMX_SPLITK_F16 : 0);
     return NMX_OK;
   }
 #define NMX_DMA_LAUNCH(SC, LSV)                                                                                                   \
@@ -889,7 +901,7 @@ static int nmx_dma_launch(NmxWideCall& call, int splits, int xcd_split, hipStrea
   else { if (ls) NMX_DMA_LAUNCH(false, true) else NMX_DMA_LAUNCH(false, false) }
 #undef NMX_DMA_LAUNCH
   NMX_LAUNCH_CHECK();
-  call.splits_done = splits;
+  call.splits_done = splits | (p.partial_f16 ? NMX_SPLITK_F16 : 0);
   return NMX_OK;
 }
 
@@ -952,6 +964,6 @@ int nmx_dma_run(NmxWideCall& call, int splits, hipStream_t stream) {
   const int rc = nmx_dma_launch(call, splits, xcd, stream);
   if (rc != NMX_OK) return rc;
   if (splits > 1 && !call.defer_reduce)
-    return nmx_splitk_reduce(call.c, reinterpret_cast<const float*>(call.scratch), splits, call.M, call.N, NMX_F16, (nmx_stream_t)stream);
+    return nmx_splitk_reduce(call.c, reinterpret_cast<const float*>(call.scratch), call.splits_done, call.M, call.N, NMX_F16, (nmx_stream_t)stream);
   return NMX_OK;
 }

@@ -151,7 +151,7 @@ extern "C" int nmx_splitk_reduce(void* out, const float* partial, int splits, in
                                  nmx_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NMX_CHECK(dtype == NMX_F16 || dtype == NMX_BF16, NMX_ERR_UNSUPPORTED, "splitk_reduce: fp16 / bf16 only");
-  NMX_CHECK(splits >= 1 && size_n % 4 == 0 && ((uintptr_t)out % 8 == 0) && ((uintptr_t)partial % 16 == 0), NMX_ERR_INVALID_ARG,
+  NMX_CHECK(NMX_SPLITK_COUNT(splits) >= 1 && size_n % 4 == 0 && ((uintptr_t)out % 8 == 0) && ((uintptr_t)partial % 16 == 0), NMX_ERR_INVALID_ARG,
             "splitk_reduce: size_n %% 4 == 0, out 8-byte and partial 16-byte aligned");
   const int64_t mn4 = (int64_t)size_m * size_n / 4;
   if (mn4 == 0) return NMX_OK;

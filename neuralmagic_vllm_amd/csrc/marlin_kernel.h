@@ -207,6 +207,7 @@ struct GemmParams {
   const int32_t* b;        // Marlin-packed weight (2:4: compressed non-zeros, Marlin-24 permutation)
   const void* meta;        // 2:4 only: [K/32, 2N] int16 CUTLASS-reordered 2-bit indices
   const void* scales;      // [num_groups, N] Marlin-permuted
+  int partial_f16 = 0;     // marlin_wide_kernel, fp16 outputs: the K-split slabs hold fp16 (NMX_SPLITK_F16)
   const void* zeros;       // ZP kernels only: [num_groups, N] fp16 -(1024 + z), permuted like the grouped scales
   const int32_t* g_idx;    // [K] or null
   const int32_t* perm;     // [K] or null
@@ -1435,6 +1436,21 @@ __global__ void splitk_reduce_kernel(scalar_t* __restrict__ c, const float* __re
   // four slabs in flight per thread (a one-load-per-iteration loop pays a full L2 / MALL round trip per split);
   // summation order stays s = 0, 1, 2, ... so the result does not depend on the batching
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (splits & NMX_SPLITK_F16) {  // fp16 slabs (the M > 64 kernels): 8 bytes = the 4 elements, same order of summation
+    const f16* ph = reinterpret_cast<const f16*>(partial);
+    const int ns = NMX_SPLITK_COUNT(splits);
+    for (int q = 0; q < ns; ++q) {
+      union { u32x2 u; f16 h[4]; } v;
+      v.u = *reinterpret_cast<const u32x2*>(ph + ((int64_t)q * mn4 + i) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += (float)v.h[j];
+    }
+    union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
+    *reinterpret_cast<u32x2*>(c + i * 4) = r.u;
+    return;
+  }
   int s = 0;
   for (; s + 4 <= splits; s += 4) {
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(s + 0) * mn4 + i) * 4);

@@ -743,6 +743,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
             o.h[0] = Scalar<scalar_t>::from_f32(v0);
             o.h[1] = Scalar<scalar_t>::from_f32(v1);
             *reinterpret_cast<uint32_t*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = o.u;
+          } else if (p.partial_f16) {
+            union { f16 h[2]; uint32_t u; } o;
+            o.h[0] = (f16)v0;
+            o.h[1] = (f16)v1;
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<f16*>(p.partial) + ((int64_t)split_id * M + m) * N + n) = o.u;
           } else {
             *reinterpret_cast<f32x2*>(p.partial + ((int64_t)split_id * M + m) * N + n) = f32x2{v0, v1};
           }
@@ -763,6 +768,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
         *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.c) + (int64_t)m * N + n) = r.u;
+      } else if (p.partial_f16) {
+        union { f16 h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
+        *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.partial) + ((int64_t)split_id * M + m) * N + n) = r.u;
       } else {
         *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
       }
@@ -941,6 +951,8 @@ int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream
     p.k_splits = std::max(1, fit);
   }
   p.partial = reinterpret_cast<float*>(call.scratch);
+  // fp16 outputs: the slabs of a K split hold fp16 partial sums (NMX_SPLITK_F16; NMX_SLAB_F32=1 keeps fp32 for A/B runs)
+  p.partial_f16 = (p.k_splits > 1 && !call.is_bf16 && nmx_tune(NMX_TUNE_SLAB_F32) == nullptr) ? 1 : 0;
   int rc;
 #ifdef NMX_WIDE_MIN  // experiment builds: fp16 int4 only (compile time)
   rc = launch_wide_kind<f16, W_INT4>(p, cfg, stream);
@@ -963,13 +975,14 @@ int nmx_wide_launch(NmxWideCall& call, const NmxWideCfg& cfg, hipStream_t stream
 #undef NMX_WIDE_KIND
 #endif
   if (rc != NMX_OK) return rc;
-  call.splits_done = p.k_splits;
+  const int coded = p.k_splits | (p.partial_f16 ? NMX_SPLITK_F16 : 0);
+  call.splits_done = coded;
   if (p.k_splits > 1 && !p.defer_reduce) {
     const int64_t mn4 = (int64_t)p.M * p.N / 4;
     if (call.is_bf16)
-      splitk_reduce_kernel<bf16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<bf16*>(p.c), p.partial, mn4, p.k_splits);
+      splitk_reduce_kernel<bf16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<bf16*>(p.c), p.partial, mn4, coded);
     else
-      splitk_reduce_kernel<f16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<f16*>(p.c), p.partial, mn4, p.k_splits);
+      splitk_reduce_kernel<f16><<<(unsigned)ceil_div64(mn4, 256), 256, 0, stream>>>(reinterpret_cast<f16*>(p.c), p.partial, mn4, coded);
     NMX_LAUNCH_CHECK();
   }
   return NMX_OK;

@@ -34,10 +34,16 @@ void nmx_set_error(const char* fmt, ...);
 
 // ---- tuning overrides (sweeps and tests only; never needed for correct results) ------------------------------------
 // The environment is read ONCE, when the library is loaded; nmx_tuning_set() (include/nmx.h) changes a value afterwards.
+// `splits` arguments of the split-K consumers / reduce entries: bits 0..7 = number of slabs, NMX_SPLITK_F16 = the slabs hold
+// fp16 instead of fp32 partial sums (round 3: the M > 64 Marlin kernels with fp16 outputs write them - half the slab traffic; the
+// reference's own global reduce passes fp16 partials between blocks too, gptq_marlin.cu global_reduce)
+#define NMX_SPLITK_F16 0x100
+#define NMX_SPLITK_COUNT(s) ((s) & 0xff)
+
 enum NmxTune {
   NMX_TUNE_GEMM_CFG = 0, NMX_TUNE_GEMM_LEAN, NMX_TUNE_GEMM_LARGE, NMX_TUNE_GEMM_LARGE_NGRP, NMX_TUNE_GEMM_WIDE,
   NMX_TUNE_ATTN_NW, NMX_TUNE_PREFILL_GQ, NMX_TUNE_MM_NO_LDS, NMX_TUNE_MM_NT, NMX_TUNE_AWQ_NO_RING, NMX_TUNE_GPTQ_NO_RING,
-  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_COUNT
+  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_SLAB_F32, NMX_TUNE_COUNT
 };
 __attribute__((visibility("hidden"))) const char* nmx_tune(int id);  // value, or nullptr when unset
 
