@@ -82,6 +82,40 @@ __device__ __forceinline__ void a_lshr(uint32_t& d, uint32_t sh_v) { asm volatil
 // measured SQ_LDS_BANK_CONFLICT = 41 % of the LDS cycles).
 __device__ __host__ __forceinline__ constexpr int a_swz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }
 
+// A wave's 128 x 64 tile of 16-bit outputs stored as WHOLE 128-byte lines (round 3, late). The accumulator layout gives a lane 4
+// consecutive columns of one row: stored from there, a wave instruction is 16 rows x 32 bytes, and the K-scan ablations priced the
+// output stores of a gate_up launch at 6.1 us (2,048 partial-line write requests per workgroup, all workgroups at once). Through a
+// wave-private LDS image with a 144-byte row stride (conflict-free ds_write_b64 / aligned ds_read_b128) a lane stores 16 bytes and
+// eight lanes cover a row's line: 512 requests per workgroup. v[mt][t] = the 4 values of row 16 mt + li, columns 16 t + 4 g ..;
+// dst = the tile's row 0 / column 0, ld in elements, rows >= rows_valid are not stored.
+#ifndef NMX_DMA_TSTORE
+#define NMX_DMA_TSTORE 1   // 0: the first form of the stores (8 bytes per lane straight from the accumulator layout), for A/B builds
+#endif
+constexpr int kTRow = 144;
+__device__ __forceinline__ void store_tile16(char* img, const u32x2 (&v)[8][4], f16* dst, int64_t ld, int rows_valid, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  if constexpr (NMX_DMA_TSTORE == 0) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (16 * mt + li < rows_valid) *reinterpret_cast<u32x2*>(dst + (int64_t)(16 * mt + li) * ld + 16 * t + 4 * g) = v[mt][t];
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<u32x2*>(img + (16 * mt + li) * kTRow + 32 * t + 8 * g) = v[mt][t];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private image: the wave's own LDS operations complete in order
+  const int r0 = lane >> 3, c = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = 8 * i + r0;
+    const u32x4 d = *reinterpret_cast<const u32x4*>(img + row * kTRow + 16 * c);
+    if (row < rows_valid) *reinterpret_cast<u32x4*>(dst + (int64_t)row * ld + 8 * c) = d;
+  }
+}
+
 struct WFrag { uint32_t w[4][4]; };   // [tile t][register m]: MFMA A operand of output columns 16 t + (lane & 15)
 struct WRaw { uint32_t r[4][4]; };    // [chunk m][word t] of k-tile g, already shifted right by 8 b
 
@@ -462,24 +496,45 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
         }
     }
     __syncthreads();
-    if (kg != 0 || wn >= HW || !col_ok) return;
+    u32x2 ov[8][4];
+    if (kg == 0 && wn < HW) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int m = m0 + mt * 16 + li;
+      for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        union { f16 h[4]; u32x2 u; } up, o;
-        up.u = ex[pair + (mt * 4 + t) * 64 + lane];
+        for (int t = 0; t < 4; ++t) {
+          union { f16 h[4]; u32x2 u; } up, o;
+          up.u = ex[pair + (mt * 4 + t) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o.h[j] = rnd_mul<f16>(silu_rnd<f16>((f16)acc[mt][t][j]), up.h[j]);
-        if (m < M) *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.act_out) + (int64_t)m * (N / 2) + n0 + 16 * t + 4 * g) = o.u;
-      }
+          for (int j = 0; j < 4; ++j) o.h[j] = rnd_mul<f16>(silu_rnd<f16>((f16)acc[mt][t][j]), up.h[j]);
+          ov[mt][t] = o.u;
+        }
     }
+    __syncthreads();  // the exchange buffer becomes the transpose images
+    if (kg != 0 || wn >= HW || !col_ok) return;
+    store_tile16(smem + wn * (128 * kTRow), ov, reinterpret_cast<f16*>(p.act_out) + (int64_t)m0 * (N / 2) + n0, N / 2, M - m0, lane);
     return;
   }
+  if constexpr (!LS) __syncthreads();  // the reduction slabs become the transpose images (LS: nothing was staged there)
   if (kg != 0 || !col_ok) return;
   if constexpr ((NMX_DABLATE & 8192) != 0) { if (acc[0][0][0] != 12345.678f) return; }  // no output stores (the K-group reduce stays)
-  // lane (g, li): D rows = the 4 consecutive output columns 16 t + 4 g + r, D col = activation row li
+  if (p.k_splits == 1 || p.partial_f16) {
+    // 16-bit outputs (the result, or an fp16 slab): whole 128-byte lines through the wave's transpose image
+    u32x2 ov[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        union { f16 h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
+        ov[mt][t] = r.u;
+      }
+    f16* dst = p.k_splits == 1 ? reinterpret_cast<f16*>(p.c) + (int64_t)m0 * N + n0
+                               : reinterpret_cast<f16*>(p.partial) + ((int64_t)split_id * M + m0) * N + n0;
+    store_tile16(smem + wn * (128 * kTRow), ov, dst, N, M - m0, lane);
+    return;
+  }
+  // fp32 slabs (NMX_SLAB_F32): lane (g, li): D rows = the 4 consecutive output columns 16 t + 4 g + r, D col = activation row li
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int m = m0 + mt * 16 + li;
@@ -487,19 +542,7 @@ __global__ __launch_bounds__(512, 2) void marlin_dma_kernel(const DmaParams p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int n = n0 + 16 * t + 4 * g;
-      if (p.k_splits == 1) {
-        union { f16 h[4]; u32x2 u; } r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
-        *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.c) + (int64_t)m * N + n) = r.u;
-      } else if (p.partial_f16) {
-        union { f16 h[4]; u32x2 u; } r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.h[j] = (f16)acc[mt][t][j];
-        *reinterpret_cast<u32x2*>(reinterpret_cast<f16*>(p.partial) + ((int64_t)split_id * M + m) * N + n) = r.u;
-      } else {
-        *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
-      }
+      *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split_id * M + m) * N + n) = acc[mt][t];
     }
   }
 }
@@ -943,6 +986,8 @@ bool nmx_dma_pick(int M, int N, int K, int num_groups, int group_size, int kind,
   // batch <= 256 of the decode step: only the long-K matrices. In the step the slabs of a K split are summed by the consumer op,
   // so MORE splits than the older dispatch takes cost there what they save here (bench.py A/B at batch 256 with qkv on 4
   // splits instead of 2: step 11.15 vs 11.09 ms); down_proj runs 8 splits either way and is 8-10 % faster on this kernel.
+  // (round 3, late, with fp16 slabs and whole-line stores: qkv on 4 splits here is 22.8 vs 24.8 us on the 64-row wide tiles, and the
+  // step still does not gain - 11.11 vs 11.09 ms; unchanged)
   if (M <= 256 && K < 8192) return false;
   // an explicit override of one of the older kernels (sweeps, their tests) keeps this one out of the way
   if (nmx_tune(NMX_TUNE_GEMM_WIDE) != nullptr || nmx_tune(NMX_TUNE_GEMM_CFG) != nullptr || nmx_tune(NMX_TUNE_GEMM_LARGE) != nullptr) return false;

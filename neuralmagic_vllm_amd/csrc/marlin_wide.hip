@@ -73,6 +73,23 @@ __device__ __forceinline__ void a_pk_fma_h(uint32_t& d, uint32_t b_s, uint32_t c
 }
 __device__ __forceinline__ void a_lshr8(uint32_t& d, uint32_t q) { asm volatile("v_lshrrev_b32 %0, 8, %1" : "=v"(d) : "v"(q)); }
 
+// Whole-line stores of a wave's (16 MT) x 64 tile of 16-bit outputs (round 3, late; marlin_dma.hip store_tile16 has the
+// measurements: the accumulator layout gives a lane 4 - 2:4: 2 - consecutive columns of a row, i.e. 16 rows x 32 (8) bytes per
+// wave instruction and 4 - 16 x the write requests of whole lines). The lanes park their pieces in a wave-private LDS image with
+// a 144-byte row stride; flush_tile16 reads 16 bytes per lane back (8 lanes = one row's 128-byte line) and stores them.
+constexpr int kTRow = 144;
+template <int MT>
+__device__ __forceinline__ void flush_tile16(const char* img, uint16_t* dst, int64_t ld, int rows_valid, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private image: the wave's own LDS operations complete in order
+  const int r0 = lane >> 3, c = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 2 * MT; ++i) {
+    const int row = 8 * i + r0;
+    const u32x4 d = *reinterpret_cast<const u32x4*>(img + row * kTRow + 16 * c);
+    if (row < rows_valid) *reinterpret_cast<u32x4*>(dst + (int64_t)row * ld + 8 * c) = d;
+  }
+}
+
 struct WFrag { uint32_t w[4][4]; };  // four MFMA operand fragments (tile t, dword)
 
 // Operation j of the int4 -> fp16 conversion of one k-step (two packed words per tile pair; tile t = column
@@ -708,25 +725,55 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
         }
     }
     __syncthreads();
-    if (wk != 0 || wn >= HW || !col_ok) return;
+    u32x2 ov[MT][NTILE];
+    if (wk == 0 && wn < HW) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = m0 + wm * 16 * MT + mt * 16 + li;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int t = 0; t < NTILE; ++t) {
-        union { scalar_t h[4]; u32x2 u; } up, o;
-        up.u = ex[pair + (mt * NTILE + t) * 64 + lane];
+        for (int t = 0; t < NTILE; ++t) {
+          union { scalar_t h[4]; u32x2 u; } up, o;
+          up.u = ex[pair + (mt * NTILE + t) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o.h[j] = rnd_mul<scalar_t>(silu_rnd<scalar_t>(Scalar<scalar_t>::from_f32(acc[mt][t][j])), up.h[j]);
-        const int n = n0 + 32 * (g >> 1) + 8 * t + 4 * (g & 1);
-        if (m < M) *reinterpret_cast<u32x2*>(reinterpret_cast<scalar_t*>(p.act_out) + (int64_t)m * (N / 2) + n) = o.u;
-      }
+          for (int j = 0; j < 4; ++j) o.h[j] = rnd_mul<scalar_t>(silu_rnd<scalar_t>(Scalar<scalar_t>::from_f32(acc[mt][t][j])), up.h[j]);
+          ov[mt][t] = o.u;
+        }
     }
+    __syncthreads();  // the exchange buffer becomes the transpose images
+    if (wk != 0 || wn >= HW || !col_ok) return;
+    char* img = smem + (wm * HW + wn) * (16 * MT * kTRow);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+        *reinterpret_cast<u32x2*>(img + (16 * mt + li) * kTRow + 2 * (32 * (g >> 1) + 8 * t + 4 * (g & 1))) = ov[mt][t];
+    flush_tile16<MT>(img, reinterpret_cast<uint16_t*>(p.act_out) + (int64_t)(m0 + wm * 16 * MT) * (N / 2) + n0, N / 2,
+                     M - m0 - wm * 16 * MT, lane);
     return;
   }
+  // 16-bit outputs (the result, or an fp16 slab of a K split) leave as whole lines through the wave's transpose image
+  const bool out16 = p.k_splits == 1 || p.partial_f16;
+  if constexpr (WK > 1) __syncthreads();  // the reduction slabs become the transpose images (WK = 1: the loop's last barrier freed the stage buffers)
   if (wk != 0 || !col_ok) return;
+  char* const timg = smem + (wm * WN + wn) * (16 * MT * kTRow);
+  uint16_t* const tdst = p.k_splits == 1 ? reinterpret_cast<uint16_t*>(p.c) + (int64_t)(m0 + wm * 16 * MT) * N + n0
+                                         : reinterpret_cast<uint16_t*>(p.partial) + ((int64_t)split_id * M + m0 + wm * 16 * MT) * N + n0;
 
   if constexpr (SP) {
+    if (out16) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            union { scalar_t h[2]; uint32_t u; } o;  // (p.partial_f16 implies scalar_t = f16)
+            o.h[0] = Scalar<scalar_t>::from_f32(acc[mt][q][r]);
+            o.h[1] = Scalar<scalar_t>::from_f32(acc[mt][2 + q][r]);
+            *reinterpret_cast<uint32_t*>(timg + (16 * mt + li) * kTRow + 2 * (8 * (4 * (g & 1) + r) + 2 * (g >> 1) + 4 * q)) = o.u;
+          }
+      flush_tile16<MT>(timg, tdst, N, M - m0 - wm * 16 * MT, lane);
+      return;
+    }
     // tiles q and 2 + q are neighbouring columns -> 2-element stores (as marlin_gemm_kernel<SP>)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -756,6 +803,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void marlin_wide_kernel(const
     return;
   }
   // lane (g, li): D rows = 4 consecutive output columns 32 (g >> 1) + 8 t + 4 (g & 1) + r, D col = activation row li
+  if (out16) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        union { scalar_t h[4]; u32x2 u; } r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[j] = Scalar<scalar_t>::from_f32(acc[mt][t][j]);
+        *reinterpret_cast<u32x2*>(timg + (16 * mt + li) * kTRow + 2 * (32 * (g >> 1) + 8 * t + 4 * (g & 1))) = r.u;
+      }
+    flush_tile16<MT>(timg, tdst, N, M - m0 - wm * 16 * MT, lane);
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + wm * 16 * MT + mt * 16 + li;
@@ -786,7 +846,8 @@ int launch_wide_cfg(const GemmParams& p, hipStream_t stream) {
   const size_t stage = (size_t)WK * 2 * BM * 128;
   const size_t red = (WK > 1) ? (size_t)(WK / 2) * WM * WN * MT * 4 * 64 * 4 * sizeof(float) : 0;
   const size_t ex = (size_t)WM * (WN / 2) * MT * 4 * 64 * 8;  // fused silu_and_mul: the up halves as fp16 / bf16
-  const size_t smem = std::max(std::max(stage, red), ex);
+  const size_t timg = (size_t)WM * WN * 16 * MT * kTRow;       // transpose images of the output stores
+  const size_t smem = std::max(std::max(std::max(stage, red), ex), timg);
   dim3 grid(ceil_div(ceil_div(p.N, 64 * WN), 8) * 8 * ceil_div(p.M, BM), p.k_splits, 1);
   auto kern = marlin_wide_kernel<scalar_t, KIND, MODE, WM, WN, WK, MT, SP, ZP>;
   if (smem > 64 * 1024)
