@@ -764,17 +764,31 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_tile_kernel(const MmPa
 
 // tile shape and K splits of scaled_mm_tile_kernel: 128 x 256 tiles when they alone give >= 128 workgroups, else
 // 128 x 128 tiles with K splits until >= 192 workgroups exist (>= 8 stages per split)
-struct TileCfg { int wn, splits, pipe; };
+struct TileCfg { int wn, splits, pipe, wm; };
 inline TileCfg mm_tile_cfg(int M, int N, int K, bool fp8) {
-  TileCfg c{4, 1, 1};
+  TileCfg c{4, 1, 1, 2};
   const int rows = ceil_div(M, 128), stages = K / 128;
   // NMX_MM_TILE="wn[,splits[,form]]" (sweeps): wn 2 / 4 = the 128- / 256-column tile, splits 0 = the rule's, form 0 = the
   // round-2 loop (fp8, wn 4: DMA, fragments read per stage; wn 2: register-staged), 1 = the fragment-pipelined DMA loop
   int force = 0, fsplits = 0;
   if (const char* e = nmx_tune(NMX_TUNE_MM_TILE)) {
-    int f = 1;
-    const int got = sscanf(e, "%d,%d,%d", &force, &fsplits, &f);
+    int f = 1, fwm = 2;
+    const int got = sscanf(e, "%d,%d,%d,%d", &force, &fsplits, &f, &fwm);
     if (got >= 3) c.pipe = f;
+    if (got >= 4 && fp8 && fwm == 4 && force == 2) {  // forced tall tile (sweeps): 256 rows x 128 columns, fragment-pipelined
+      c.wn = 2, c.wm = 4, c.pipe = 1;
+      c.splits = fsplits > 0 ? fsplits : 1;
+      return c;
+    }
+  }
+  // fp8, 128 < M (round 3, late): TALL tiles - 256 rows x 128 columns, same eight waves and the same fragment-pipelined loop -
+  // fetch every weight line once per 256 rows. Where they alone fill the chip they beat the 128 x 256 tile (gate_up M = 256:
+  // 43.7 vs 45.4 us, M = 512: 75.1 vs 81.5; same-process A/B, gpurun_out/mm_tall1.txt -> profiles/r03_fp8_tile_experiments.txt),
+  // and with two K splits the mid-size matrices from 512 rows (qkv M = 512: 22.3 vs 28.8 us); o / down stay as they were.
+  if (fp8 && force == 0 && c.pipe != 0 && M > 128) {
+    const int tall = ceil_div(M, 256) * ceil_div(N, 128);
+    if (tall >= 192) return TileCfg{2, 1, 1, 4};
+    if (M > 256 && tall * 2 >= 160 && tall * 2 <= 256 && stages / 2 >= 8 && K < 8192) return TileCfg{2, 2, 1, 4};
   }
   // long K with few tiles (down: 14336 x 4096): the 256-column DMA tile with K splits - int8 from M = 65, fp8 above M = 256
   // (fp8, round 3: the fragment-pipelined 128-column tile is ahead up to there - M = 128: 24.8 vs 29.2 us, M = 256: 31.9 vs
@@ -830,9 +844,9 @@ int launch_mm_tile(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
     p.k_splits = std::max(1, fit);
   }
   p.partial = scratch;
-  dim3 grid(ceil_div(p.N, 64 * c.wn), p.k_splits, ceil_div(p.M, 128));
+  dim3 grid(ceil_div(p.N, 64 * c.wn), p.k_splits, ceil_div(p.M, 64 * c.wm));
   const bool pipe = FP8 && c.pipe != 0;
-  const int smem = ((c.wn == 4 || pipe) ? 3 : 2) * 64 * (2 + c.wn) * 128;
+  const int smem = ((c.wn == 4 || pipe) ? 3 : 2) * 64 * (c.wm + c.wn) * 128;
   auto go = [&](auto kern, int threads) {
     NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     kern<<<grid, threads, smem, stream>>>(p);
@@ -840,7 +854,8 @@ int launch_mm_tile(MmParams& p, void* scratch, int64_t scratch_bytes, hipStream_
   };
   if constexpr (FP8) {
     if (pipe) {
-      const int rc = c.wn == 4 ? go(scaled_mm_tile_kernel<out_t, true, 2, 4, 3, true>, 512)
+      const int rc = c.wm == 4 ? go(scaled_mm_tile_kernel<out_t, true, 4, 2, 3, true>, 512)
+                   : c.wn == 4 ? go(scaled_mm_tile_kernel<out_t, true, 2, 4, 3, true>, 512)
                                : go(scaled_mm_tile_kernel<out_t, true, 2, 2, 3, true>, 256);
       if (rc != NMX_OK) return rc;
     }

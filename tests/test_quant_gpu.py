@@ -95,11 +95,14 @@ def test_cutlass_scaled_mm(ops, m, n, k, per_act_token, per_out_ch, is_fp8, use_
 
 @pytest.mark.parametrize("m,n,k", [(256, 16384, 1024), (129, 16400, 256), (300, 1104, 2048), (256, 6144, 4096), (65, 64, 128)])
 @pytest.mark.parametrize("is_fp8", [True, False])
-@pytest.mark.parametrize("tile", [None, "0"])
+@pytest.mark.parametrize("tile", [None, "0", "2,0,1,4", "2,2,1,4"])
 def test_scaled_mm_tile_kernel(ops, tune, m, n, k, is_fp8, tile):
-    """M > 64: scaled_mm_tile_kernel (128 x 256 tiles when they fill the chip, else 128 x 128 with K splits), ragged M / N,
+    """M > 64: scaled_mm_tile_kernel (128 x 256 tiles when they fill the chip, else 128 x 128 with K splits; fp8: the forced
+    TALL 256 x 128 tile, alone and with two K splits), ragged M / N,
     per-row and per-column scales with bias; checked against the fp32 product computed on the device and against the
     per-wave kernel (NMX_MM_TILE=0) through the same bar. int8 accumulates exactly: the two kernels must agree bit for bit."""
+    if tile is not None and tile.endswith(",4") and not is_fp8:
+        pytest.skip("the tall tile is an fp8 form")
     seed_all(5)
     out_dtype = torch.bfloat16 if is_fp8 else torch.float16
     if is_fp8:
@@ -120,7 +123,7 @@ def test_scaled_mm_tile_kernel(ops, tune, m, n, k, is_fp8, tile):
         assert torch.equal(out, ops.cutlass_scaled_mm(a, b.t(), sa, sb, out_dtype, bias))
 
 
-@pytest.mark.parametrize("m", [64, 256])
+@pytest.mark.parametrize("m", [64, 256, 512])
 @pytest.mark.parametrize("k,n", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
 def test_scaled_mm_llama3_8b_shapes(ops, k, n, m):
     """configs[3] (Llama-3-8B fp8 W8A8) at its own workload: the four (K, N) `bench.py --config fp8` times, default dispatch

@@ -112,6 +112,16 @@ def main():
             by = K * N // 2 + (K // 128) * N * 2 + 2 * M * K + 2 * M * N
             only = os.environ.get("LEAN_SWEEP_ONLY")
             for cfg in (only.split(";") if only else cfgs_for(name, M)):
+                if cfg.startswith("T:"):  # yardstick only: dense fp16 torch.matmul (hipBLASLt) on 32 distinct fp16 weights of the shape
+                    dws = [torch.randn(K, N, dtype=torch.float16, device=dev) * 0.01 for _ in range(8 if K * N > 5e7 else NL)]
+
+                    def run_t():
+                        for i in range(NL):
+                            torch.matmul(x, dws[i % len(dws)])
+                    us = time_graph(run_t) / NL
+                    print(f"{'hipBLASLt-fp16':18} {name:8} M={M:4d} {cfg:12} {us:7.2f} us  {(2 * K * N + 2 * M * K + 2 * M * N) / us / 1e3:7.0f} GB/s  {2.0 * M * K * N / us / 1e6:7.1f} TFLOP/s  (dense fp16 yardstick)", flush=True)
+                    del dws
+                    continue
                 set_cfg(cfg)
                 try:
                     out = ops.gptq_marlin_gemm(x, ws[0][0], ws[0][1], e, e, wsp, 4, M, N, K, True).float()

@@ -49,6 +49,17 @@ def main():
             ref = ops.cutlass_scaled_mm(a, ws[0].t(), sa, sb, torch.float16).float()
             exact = (a.float() @ ws[0].float().t()) * (0.02 * 0.01)
             for cfg in cfgs:
+                if cfg == "T":  # yardstick only: torch._scaled_mm (hipBLASLt), never part of the product path
+                    try:
+                        def run_t():
+                            for w in ws:
+                                torch._scaled_mm(a, w.t(), scale_a=sa, scale_b=sb, out_dtype=torch.float16)
+                        us = time_graph(run_t) / NL
+                        print(f"{name:8} M={M:4d} {'hipBLASLt':8} {us:7.2f} us  {2.0 * M * K * N / us / 1e6:7.1f} TFLOP/s  (torch._scaled_mm yardstick)", flush=True)
+                    except Exception as ex:  # noqa: BLE001
+                        print(f"{name:8} M={M:4d} hipBLASLt FAILED {ex}", flush=True)
+                        torch.cuda.synchronize()
+                    continue
                 _lib.set_tuning("NMX_MM_TILE", None if cfg == "D" else cfg)
                 try:
                     out = ops.cutlass_scaled_mm(a, ws[0].t(), sa, sb, torch.float16).float()
