@@ -100,6 +100,21 @@ int nmx_paged_attention_v2_absmax(void* out, float* absmax, float* exp_sums, flo
                                   int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
                                   nmx_stream_t stream);
 
+/* paged_attention_v2 with the caller's choice of partition size (no reference counterpart: the reference fixes 512 tokens,
+ * csrc/attention/attention_kernels.cu:847, vllm/attention/ops/paged_attn.py:17). At small batch 512-token partitions leave
+ * most CUs idle; nmx_paged_attention_partition_size() answers the size this library recommends for a launch (512, or 256 / 128
+ * while the finer split still fits one round of workgroups), and nmx_paged_attention_v2_ps() runs the same kernels with it.
+ * exp_sums / max_logits: float32 [num_seqs, num_heads, P], tmp_out: [num_seqs, num_heads, P, head_size] in the query dtype,
+ * P = ceil(max_seq_len / partition_size); partition_size 64 .. 512, a multiple of 64; absmax as above, or NULL. */
+int nmx_paged_attention_partition_size(int num_seqs, int num_heads, int num_kv_heads, int max_seq_len);
+int nmx_paged_attention_v2_ps(void* out, float* absmax, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+                              const void* key_cache, const void* value_cache, int num_seqs, int num_heads, int num_kv_heads,
+                              int head_size, int block_size, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                              float scale, const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                              int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
+                              int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
+                              int partition_size, nmx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * KV-cache ops. Replace csrc/cache_kernels.cu (schema csrc/torch_bindings.cpp:207-244, csrc/cache.h:8-32).
  * ---------------------------------------------------------------------------------------------------------- */

@@ -187,7 +187,7 @@ def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torc
 def _attn_common(fn, head_args, query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,
                  block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
                  blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
-                 blocksparse_head_sliding_step):
+                 blocksparse_head_sliding_step, tail_args=()):
     _dev(query)
     if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
         raise RuntimeError("block_tables and seq_lens must be int32")
@@ -201,7 +201,23 @@ def _attn_common(fn, head_args, query, key_cache, value_cache, num_kv_heads, sca
            c_int(block_tables.size(1)), _p(seq_lens), c_int(max_seq_len), _p(alibi_slopes), c_int(_dt(query)),
            c_int(_kv(kv_cache_dtype)), c_f(kv_scale), c_int(tp_rank), c_int(blocksparse_local_blocks),
            c_int(blocksparse_vert_stride), c_int(blocksparse_block_size), c_int(blocksparse_head_sliding_step),
-           _stream(query)))
+           *tail_args, _stream(query)))
+
+
+def _v2_fine_partition(query, num_kv_heads, max_seq_len):
+    """Partition size the v2 ops run with: the contract's 512 tokens, or - at small batch, where 512-token partitions leave
+    most CUs idle - what nmx_paged_attention_partition_size() answers. With a finer split the op works on temporaries of its
+    own (the caller's exp_sums / max_logits / tmp_out are sized for 512-token partitions and hold nothing a caller may read
+    afterwards: vllm/attention/ops/paged_attn.py:148-158 allocates them per call)."""
+    ps = _lib.lib().nmx_paged_attention_partition_size(c_int(query.shape[0]), c_int(query.shape[1]), c_int(num_kv_heads),
+                                                       c_int(max_seq_len))
+    if ps >= 512:
+        return 512, None
+    num_seqs, num_heads, head_size = query.shape
+    parts = (max_seq_len + ps - 1) // ps
+    tmp = torch.empty(num_seqs, num_heads, parts, head_size, dtype=query.dtype, device=query.device)
+    sums = torch.empty(2, num_seqs, num_heads, parts, dtype=torch.float32, device=query.device)
+    return ps, (sums[0], sums[1], tmp)
 
 
 def paged_attention_v1(
@@ -253,6 +269,13 @@ def paged_attention_v2(
     blocksparse_block_size: int = 64,
     blocksparse_head_sliding_step: int = 0,
 ) -> None:
+    ps, own = _v2_fine_partition(query, num_kv_heads, max_seq_len)
+    if own is not None:
+        _attn_common(_lib.lib().nmx_paged_attention_v2_ps, (_p(out), _p(None), _p(own[0]), _p(own[1]), _p(own[2])), query, key_cache,
+                     value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
+                     kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                     blocksparse_head_sliding_step, tail_args=(c_int(ps), ))
+        return
     _attn_common(_lib.lib().nmx_paged_attention_v2, (_p(out), _p(exp_sum), _p(max_logits), _p(tmp_out)), query,
                  key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
                  alibi_slopes, kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
@@ -279,6 +302,13 @@ def paged_attention_v2_absmax(out, exp_sum, max_logits, tmp_out, query, key_cach
     """paged_attention_v2 with the same by-product (one maximum per head and sequence, written by the reduce kernel)."""
     n = _lib.lib().nmx_paged_attention_absmax_numel(c_int(query.shape[0]), c_int(query.shape[1]), c_int(num_kv_heads), c_int(1))
     amax = torch.empty(n, dtype=torch.float32, device=query.device)
+    ps, own = _v2_fine_partition(query, num_kv_heads, max_seq_len)
+    if own is not None:
+        _attn_common(_lib.lib().nmx_paged_attention_v2_ps, (_p(out), _p(amax), _p(own[0]), _p(own[1]), _p(own[2])), query, key_cache,
+                     value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
+                     kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                     blocksparse_head_sliding_step, tail_args=(c_int(ps), ))
+        return amax
     _attn_common(_lib.lib().nmx_paged_attention_v2_absmax, (_p(out), _p(amax), _p(exp_sum), _p(max_logits), _p(tmp_out)), query,
                  key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
                  kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,

@@ -43,7 +43,7 @@ void nmx_set_error(const char* fmt, ...);
 enum NmxTune {
   NMX_TUNE_GEMM_CFG = 0, NMX_TUNE_GEMM_LEAN, NMX_TUNE_GEMM_LARGE, NMX_TUNE_GEMM_LARGE_NGRP, NMX_TUNE_GEMM_WIDE,
   NMX_TUNE_ATTN_NW, NMX_TUNE_PREFILL_GQ, NMX_TUNE_MM_NO_LDS, NMX_TUNE_MM_NT, NMX_TUNE_AWQ_NO_RING, NMX_TUNE_GPTQ_NO_RING,
-  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_SLAB_F32, NMX_TUNE_COUNT
+  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_SLAB_F32, NMX_TUNE_ATTN_PART, NMX_TUNE_COUNT
 };
 __attribute__((visibility("hidden"))) const char* nmx_tune(int id);  // value, or nullptr when unset
 

@@ -37,7 +37,7 @@
 
 namespace {
 
-constexpr int kPartitionSize = 512;  // fixed by the op contract (attention_kernels.cu:847)
+constexpr int kPartitionSize = 512;  // the op contract's partition (attention_kernels.cu:847); nmx_paged_attention_v2_ps takes its own
 constexpr int kTile = 32;            // tokens per wave iteration
 
 struct AttnParams {
@@ -55,6 +55,7 @@ struct AttnParams {
   int num_heads, num_kv_heads, q_per_kv, q_tiles;
   int max_blocks_per_seq, block_size, bs_shift;
   int partitioned, max_num_partitions;
+  int part_size;      // tokens per partition (v2: 512 by contract; nmx_paged_attention_v2_ps: 64 .. 512, a multiple of 64)
   int sparse, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step;
   // optional (nmx_paged_attention_v1/v2_absmax): max |out| of what a workgroup (v1: one per kv head x q tile x sequence) / the
   // v2 reduce (one per head x sequence) wrote, so that a dynamic fp8 quantisation of the attention output needs no absmax pass
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
 
   int tok_begin = 0, tok_end = seq_len;
   if (p.partitioned) {
-    tok_begin = part * kPartitionSize;
+    tok_begin = part * p.part_size;
     if (tok_begin >= seq_len) return;  // attention_kernels.cu:116-119
-    tok_end = min(seq_len, tok_begin + kPartitionSize);
+    tok_end = min(seq_len, tok_begin + p.part_size);
   }
 
   const int lane = threadIdx.x & 63;
@@ -484,9 +485,9 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
   const int seq_len = p.seq_lens[seq];
   int tok_begin = 0, tok_end = seq_len;
   if (p.partitioned) {
-    tok_begin = part * kPartitionSize;
+    tok_begin = part * p.part_size;
     if (tok_begin >= seq_len) return;
-    tok_end = min(seq_len, tok_begin + kPartitionSize);
+    tok_end = min(seq_len, tok_begin + p.part_size);
   }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -769,10 +770,10 @@ __global__ void paged_attention_v2_reduce_kernel(scalar_t* __restrict__ out, con
                                                  const float* __restrict__ max_logits,
                                                  const scalar_t* __restrict__ tmp_out,
                                                  const int32_t* __restrict__ seq_lens, int max_num_partitions,
-                                                 int head_size, float* __restrict__ absmax) {
+                                                 int head_size, float* __restrict__ absmax, int part_size) {
   const int head = blockIdx.x, num_heads = gridDim.x, seq = blockIdx.y;
   const int seq_len = seq_lens[seq];
-  const int np = (seq_len + kPartitionSize - 1) / kPartitionSize;
+  const int np = (seq_len + part_size - 1) / part_size;
   const int64_t pb = ((int64_t)seq * num_heads + head) * max_num_partitions;
   scalar_t* o = out + ((int64_t)seq * num_heads + head) * head_size;
   const scalar_t* tp = tmp_out + pb * head_size;
@@ -831,9 +832,9 @@ __global__ __launch_bounds__(256) void paged_attention_f32_kernel(const AttnPara
   const int seq_len = p.seq_lens[seq];
   int tok_begin = 0, tok_end = seq_len;
   if (p.partitioned) {
-    tok_begin = part * kPartitionSize;
+    tok_begin = part * p.part_size;
     if (tok_begin >= seq_len) return;
-    tok_end = min(seq_len, tok_begin + kPartitionSize);
+    tok_end = min(seq_len, tok_begin + p.part_size);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kvh = head / p.q_per_kv;
@@ -994,7 +995,7 @@ int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream
     const char* e = nmx_tune(NMX_TUNE_ATTN_FP8W);
     if (p.block_size >= 16 && !(e != nullptr && atoi(e) == 0)) {
       const long wgs = (long)p.num_kv_heads * p.q_tiles * num_seqs * num_partitions;
-      int nw = wgs <= 128 ? 8 : 4;
+      int nw = (wgs <= 128 && p.part_size > 256) ? 8 : 4;
       if (const char* n = nmx_tune(NMX_TUNE_ATTN_NW)) nw = atoi(n) == 8 ? 8 : 4;
       if (nw == 8) return launch_attn_fp8w<scalar_t, KV, D, 8>(p, num_seqs, num_partitions, stream);
       return launch_attn_fp8w<scalar_t, KV, D, 4>(p, num_seqs, num_partitions, stream);
@@ -1005,7 +1006,7 @@ int launch_attn(const AttnParams& p, int num_seqs, int num_partitions, hipStream
   // 512-token partition, all K / V requests of the partition in flight at once) instead of 4.
   if constexpr (D <= 128) {
     const long wgs = (long)p.num_kv_heads * p.q_tiles * num_seqs * num_partitions;
-    int nw = wgs <= 128 ? 8 : 4;
+    int nw = (wgs <= 128 && p.part_size > 4 * kTile) ? 8 : 4;  // (a partition of <= 4 tiles: one tile per wave)
     if (const char* e = nmx_tune(NMX_TUNE_ATTN_NW)) nw = atoi(e) == 8 ? 8 : 4;  // sweeps / tests
     if (nw == 8) return launch_attn_nw<scalar_t, KV, D, 8>(p, num_seqs, num_partitions, stream);
   }
@@ -1042,7 +1043,9 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
                   float scale, const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
                   int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
                   int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
-                  hipStream_t stream) {
+                  hipStream_t stream, int part_size = kPartitionSize) {
+  NMX_CHECK(part_size >= 64 && part_size <= kPartitionSize && part_size % 64 == 0, NMX_ERR_INVALID_ARG,
+            "paged_attention: partition size %d (64 .. 512, a multiple of 64)", part_size);
   NMX_CHECK(block_size == 8 || block_size == 16 || block_size == 32, NMX_ERR_UNSUPPORTED,
             "Unsupported block size: %d", block_size);
   NMX_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, NMX_ERR_INVALID_ARG,
@@ -1081,8 +1084,9 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
   p.block_size = block_size;
   p.bs_shift = block_size == 8 ? 3 : (block_size == 16 ? 4 : 5);
   p.partitioned = partitioned ? 1 : 0;
-  const int num_partitions = partitioned ? (max_seq_len + kPartitionSize - 1) / kPartitionSize : 1;
+  const int num_partitions = partitioned ? (max_seq_len + part_size - 1) / part_size : 1;
   p.max_num_partitions = num_partitions;
+  p.part_size = part_size;
   p.sparse = bs_vert_stride > 1 ? 1 : 0;  // attention_kernels.cu:822
   p.tp_rank = tp_rank;
   p.bs_local_blocks = bs_local_blocks;
@@ -1103,14 +1107,14 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
   if (dtype == NMX_F32)
     paged_attention_v2_reduce_kernel<float><<<rgrid, 64, rsmem, stream>>>((float*)out, exp_sums, max_logits,
                                                                           (const float*)tmp_out, seq_lens, num_partitions,
-                                                                          head_size, nullptr);
+                                                                          head_size, nullptr, part_size);
   else if (dtype == NMX_F16)
     paged_attention_v2_reduce_kernel<f16><<<rgrid, 64, rsmem, stream>>>((f16*)out, exp_sums, max_logits, (const f16*)tmp_out,
-                                                                        seq_lens, num_partitions, head_size, absmax);
+                                                                        seq_lens, num_partitions, head_size, absmax, part_size);
   else
     paged_attention_v2_reduce_kernel<bf16><<<rgrid, 64, rsmem, stream>>>((bf16*)out, exp_sums, max_logits,
                                                                          (const bf16*)tmp_out, seq_lens, num_partitions,
-                                                                         head_size, absmax);
+                                                                         head_size, absmax, part_size);
   NMX_LAUNCH_CHECK();
   return NMX_OK;
 }
@@ -1188,4 +1192,38 @@ extern "C" int nmx_paged_attention_v2_absmax(void* out, float* absmax, float* ex
                        block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
                        kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
                        (hipStream_t)stream);
+}
+
+// ---- v2 with the caller's choice of partition size (round 3, late; no reference counterpart). At small batch the 512-token
+// partitions of the op contract leave most CUs idle (batch 1 x 8 kv heads x 2 partitions = 16 workgroups, each streaming its
+// 256 KiB of K / V at ONE CU's rate): the decode mirror of PagedAttention.forward_decode asks
+// nmx_paged_attention_partition_size() and, when it answers less than 512, allocates its own exp_sums / max_logits / tmp_out
+// for ceil(max_seq_len / partition_size) partitions and calls this entry. Same arithmetic per partition and the same reduce
+// kernel; only the split of the softmax sum differs (as between v1 and v2). absmax may be null.
+extern "C" int nmx_paged_attention_partition_size(int num_seqs, int num_heads, int num_kv_heads, int max_seq_len) {
+  if (num_seqs <= 0 || num_heads <= 0 || num_kv_heads <= 0) return kPartitionSize;
+  const int q_tiles = (num_heads / num_kv_heads + 15) / 16;
+  int ps = kPartitionSize;
+  if (const char* e = nmx_tune(NMX_TUNE_ATTN_PART)) {  // sweeps / tests
+    const int v = atoi(e);
+    return (v >= 64 && v <= kPartitionSize && v % 64 == 0) ? v : kPartitionSize;
+  }
+  // halve while the finer split still fits one round of the 256 CUs and a partition keeps >= 128 tokens
+  while (ps > 128 && (long)num_seqs * num_kv_heads * q_tiles * ((max_seq_len + ps / 2 - 1) / (ps / 2)) <= 256) ps /= 2;
+  return ps;
+}
+
+extern "C" int nmx_paged_attention_v2_ps(void* out, float* absmax, float* exp_sums, float* max_logits, void* tmp_out,
+                                         const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+                                         int num_heads, int num_kv_heads, int head_size, int block_size, int64_t q_stride,
+                                         int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                                         const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                                         int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale,
+                                         int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
+                                         int bs_head_sliding_step, int partition_size, nmx_stream_t stream) {
+  return run_attention(true, out, absmax, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+                       num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
+                       block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
+                       kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
+                       (hipStream_t)stream, partition_size);
 }

@@ -286,3 +286,57 @@ def test_paged_attention_absmax(ops, version, kv_dtype, dtype, nq, nkv, head_siz
     q1, s1 = ops.scaled_fp8_quant_partials(flat, amax)
     q0, s0 = ops.scaled_fp8_quant(flat)
     assert torch.equal(s0, s1) and torch.equal(q0.view(torch.uint8), q1.view(torch.uint8))
+
+
+@pytest.mark.parametrize("part", ["64", "128", "256", None])
+@pytest.mark.parametrize("kv_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16, torch.float])
+@pytest.mark.parametrize("num_seqs,nq,nkv,head_size", [(1, 32, 8, 128), (3, 12, 12, 64), (2, 40, 2, 128)])
+def test_paged_attention_v2_fine_partitions(ops, tune, part, kv_dtype, dtype, num_seqs, nq, nkv, head_size):
+    """Round 3 (late): at small batch paged_attention_v2 / v2_absmax split a sequence into partitions finer than the contract's
+    512 tokens (own temporaries, nmx_paged_attention_v2_ps). Forced sizes (NMX_ATTN_PART) and the library's own choice
+    (None: 1 - 3 sequences take 128- or 256-token partitions here) against the oracle's v2 and the fp32 restatement through the
+    reference's bars; the absmax variant writes the same bits and exact maxima; the caller's temporaries stay untouched."""
+    if dtype == torch.float and (kv_dtype != "auto" or part not in ("128", None)):
+        pytest.skip("float32 queries covered on a subset")
+    seed_all(nq + head_size + num_seqs)
+    block_size = 16
+    scale = float(head_size**-0.5)
+    q = torch.empty(num_seqs, nq, head_size, dtype=dtype).uniform_(-scale, scale)
+    seq_lens = [1024, 129, 577][:num_seqs]
+    max_len = max(seq_lens)
+    mb = (max_len + block_size - 1) // block_size
+    bt = torch.tensor([[random.randint(0, 255) for _ in range(mb)] for _ in range(num_seqs)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(256, block_size, 1, nkv, head_size, kv_dtype, dtype)
+    kv_scale = 0.75 if kv_dtype != "auto" else 1.0
+    tune(NMX_ATTN_PART=part)
+    from neuralmagic_vllm_amd import _lib
+    ps = _lib.lib().nmx_paged_attention_partition_size(num_seqs, nq, nkv, max_len)
+    assert ps == (int(part) if part is not None else ps) and ps < 512  # every case here takes the fine path
+    qg, kc, vc, btg, slg = q.to(DEV), kcs[0].to(DEV), vcs[0].to(DEV), bt.to(DEV), sl.to(DEV)
+    P = (max_len + PARTITION - 1) // PARTITION
+    tmp = torch.full((num_seqs, nq, P, head_size), 7.0, dtype=dtype, device=DEV)
+    es = torch.full((num_seqs, nq, P), 7.0, dtype=torch.float32, device=DEV)
+    ml = torch.full((num_seqs, nq, P), 7.0, dtype=torch.float32, device=DEV)
+    out = torch.full_like(qg, float("nan"))
+    ops.paged_attention_v2(out, es, ml, tmp, qg, kc, vc, nkv, scale, btg, slg, block_size, max_len, None, kv_dtype, kv_scale)
+    torch.cuda.synchronize()
+    assert bool((tmp == 7.0).all()) and bool((es == 7.0).all()) and bool((ml == 7.0).all())
+    orc = run_oracle("v2", q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
+    atol = 1e-3 if kv_dtype == "auto" else 1e-2
+    torch.testing.assert_close(out.cpu().float(), orc.float(), atol=atol, rtol=1e-5)
+    if kv_dtype == "auto":
+        ref = ref_single_query_cached_kv_attention(q, nq // nkv, kcs[0], vcs[0], bt, sl, scale, None)
+        torch.testing.assert_close(out.cpu().float(), ref, atol=1e-3, rtol=1e-5)
+    if dtype != torch.float:
+        out2 = torch.full_like(qg, float("nan"))
+        amax = ops.paged_attention_v2_absmax(out2, es, ml, tmp, qg, kc, vc, nkv, scale, btg, slg, block_size, max_len, None,
+                                             kv_dtype, kv_scale)
+        torch.cuda.synchronize()
+        assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+        assert torch.equal(amax.view(num_seqs, nq), out.float().abs().amax(dim=-1))
+    # the forced size through the C-ABI's checks
+    if part == "64":
+        tune(NMX_ATTN_PART="96")  # not a multiple of 64: the library answers the contract's 512
+        assert _lib.lib().nmx_paged_attention_partition_size(num_seqs, nq, nkv, max_len) == 512
