@@ -101,6 +101,8 @@ def parse():
     ap.add_argument("--attn", choices=["auto", "v1", "v2"], default="auto", help="decode attention op: auto = the reference's rule "
                     "(paged_attn.py:120-121)")
     ap.add_argument("--no-act-fuse", action="store_true", help="int4: gate_up GEMM and silu_and_mul as two ops (A/B of the fused epilogue)")
+    ap.add_argument("--no-norm-fuse", action="store_true", help="int4: fused_add_rms_norm and the GEMM behind it as two ops (A/B of the "
+                    "norm-fused GEMM prologue at batch <= 4)")
     ap.add_argument("--no-attn-absmax", action="store_true", help="fp8: separate absmax pass over the attention output (A/B of paged_attention_v1/v2_absmax)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,6 +155,7 @@ class Llama3Decode:
         self.fuse = False  # int4 only: deferred split-K reduction + rotary / cache fusion (set by main)
         self.act_fuse = True  # int4: gate_up + silu_and_mul as one op (set by main)
         self.attn_absmax = True  # fp8: paged attention leaves the maxima of its output (set by main)
+        self.norm_fuse = True  # int4: fused_add_rms_norm + the GEMM behind it as one op (one launch at batch <= 4; set by main)
         self.n_layers = n_layers
         self.variant = variant
         self.kv_dtype = VARIANTS[variant]["kv"]
@@ -292,16 +295,29 @@ class Llama3Decode:
         resid = h
         x = torch.empty_like(h)
         ops.rms_norm(x, h, self.layers[0]["ln1"], 1e-5)
+        qkv_next = None
         for li, lw in enumerate(self.layers):
             kc, vc = self.kv[li]
-            qkv = ops.rope_reshape_and_cache(self.positions, gemm(x, lw["qkv"], "qkv"), nh, nkv, D, self.cos_sin_cache, kc, vc,
+            qkv_g = qkv_next if qkv_next is not None else gemm(x, lw["qkv"], "qkv")
+            qkv_next = None
+            qkv = ops.rope_reshape_and_cache(self.positions, qkv_g, nh, nkv, D, self.cos_sin_cache, kc, vc,
                                              self.slot_mapping, self.kv_dtype, self.kv_scale)
             a = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li)
             o = gemm(a.view(-1, nh * D), lw["o"], "o")
             if self.all_reduce is not None:
                 self.all_reduce(o.materialize())
-            h = ops.fused_add_rms_norm_splitk(o, resid, lw["ln2"], 1e-5)
-            if self.variant == "int4" and self.act_fuse:  # the activation runs in the GEMM's epilogue where the launch has no K split
+            if self.variant == "int4" and self.act_fuse and self.norm_fuse:
+                # post-attention norm + gate_up + activation: one op (one launch at batch <= 4, else norm consumer + GEMM)
+                K, N = self.shapes["gate_up"]
+                w = lw["gate_up"]
+                act, resid = ops.fused_add_rms_norm_gptq_marlin_gemm(o, resid, lw["ln2"], 1e-5, w[0], w[1], e, e, ws, 4, o.out.shape[0],
+                                                                     N, K, True, silu_and_mul=True)
+                h = None
+            else:
+                h = ops.fused_add_rms_norm_splitk(o, resid, lw["ln2"], 1e-5)
+            if h is None:
+                pass
+            elif self.variant == "int4" and self.act_fuse:  # the activation runs in the GEMM's epilogue where the launch has no K split
                 K, N = self.shapes["gate_up"]
                 w = lw["gate_up"]
                 act = ops.gptq_marlin_gemm_silu_and_mul(h, w[0], w[1], e, e, ws, 4, h.shape[0], N, K, True)
@@ -312,7 +328,14 @@ class Llama3Decode:
             if self.all_reduce is not None:
                 self.all_reduce(d.materialize())
             nxt = self.layers[li + 1]["ln1"] if li + 1 < self.n_layers else self.final_ln
-            x = ops.fused_add_rms_norm_splitk(d, resid, nxt, 1e-5)
+            if self.variant == "int4" and self.norm_fuse and li + 1 < self.n_layers:
+                # the next layer's input norm + qkv projection: one op (one launch at batch <= 4)
+                K, N = self.shapes["qkv"]
+                w = self.layers[li + 1]["qkv"]
+                qkv_next, resid = ops.fused_add_rms_norm_gptq_marlin_gemm(d, resid, nxt, 1e-5, w[0], w[1], e, e, ws, 4, d.out.shape[0],
+                                                                          N, K, True)
+            else:
+                x = ops.fused_add_rms_norm_splitk(d, resid, nxt, 1e-5)
         logits = torch.matmul(x, self.lm_head.t())
         if self.all_gather is not None:
             logits = self.all_gather(logits)
@@ -623,6 +646,7 @@ def main():
     awq_fusable = args.config.startswith("awq70b") and not args.awq_op and args.batch >= 128
     model.act_fuse = not args.no_act_fuse
     model.attn_absmax = not args.no_attn_absmax
+    model.norm_fuse = not args.no_norm_fuse
     model.fuse = (args.config in ("int4", "fp8", "sparse24") or awq_fusable) and not args.no_fuse and (args.config != "fp8" or tp == 0)
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()

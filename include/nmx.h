@@ -209,6 +209,24 @@ int nmx_gptq_marlin_gemm_silu_and_mul(const void* a, const int32_t* b_q_weight, 
                                       const int32_t* perm, void* c, void* act_out, int64_t workspace_numel, void* scratch,
                                       int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits,
                                       int num_groups, int is_k_full, int dtype, nmx_stream_t stream);
+
+/* fused_add_rms_norm + gptq_marlin_gemm as ONE launch at batch <= 4 (no reference counterpart: the reference runs
+ * ops.fused_add_rms_norm (csrc/layernorm_kernels.cu:258-291) and the GEMM one after the other, vllm/model_executor/models/
+ * llama.py:205-230). A = fused_add_rms_norm of the producer GEMM's deferred K-split slabs:
+ *   x = round(sum_s norm_partial[s]) + residual_in;  residual_out = x (must not alias residual_in);
+ *   A = round(round(x * rsqrt(mean(x^2) + epsilon)) * norm_weight)
+ * computed in the prologue of every workgroup, then gptq_marlin_gemm on A: act_out == NULL leaves c or K-split slabs and
+ * *splits_out as nmx_gptq_marlin_gemm_deferred does, act_out != NULL writes silu_and_mul of the result as
+ * nmx_gptq_marlin_gemm_silu_and_mul does. norm_splits: slab count (>= 2) | NMX_SPLITK_F16. Bit-identical to the unfused
+ * sequence. nmx_gptq_marlin_gemm_norm_supported() says which shapes are served (fp16, 4 bits, no act-order, size_m <= 4,
+ * the decode kernel's shapes); others return NMX_ERR_UNSUPPORTED. */
+int nmx_gptq_marlin_gemm_norm_supported(int size_m, int size_n, int size_k, int num_groups, int num_bits, int dtype,
+                                        int with_act);
+int nmx_gptq_marlin_gemm_norm(const float* norm_partial, int norm_splits, const void* residual_in, void* residual_out,
+                              const void* norm_weight, float epsilon, const int32_t* b_q_weight, const void* b_scales, void* c,
+                              void* act_out, int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int size_m,
+                              int size_n, int size_k, int num_bits, int num_groups, int dtype, int* splits_out,
+                              nmx_stream_t stream);
 /* fused_add_rms_norm (csrc/layernorm_kernels.cu:258-291) on x = round(sum_s partial[s]): residual += x,
  * input_out = rms_norm(residual) * weight. partial [splits, num_tokens, hidden] fp32, splits >= 2. */
 int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int splits, void* residual, const void* weight,

@@ -639,6 +639,49 @@ def gptq_marlin_gemm_silu_and_mul(a: torch.Tensor, b_q_weight: torch.Tensor, b_s
     return act
 
 
+def fused_add_rms_norm_gptq_marlin_gemm(g: DeferredGemm, residual: torch.Tensor, norm_weight: torch.Tensor, epsilon: float,
+                                        b_q_weight: torch.Tensor, b_scales: torch.Tensor, g_idx: torch.Tensor, perm: torch.Tensor,
+                                        workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int, size_k: int,
+                                        is_k_full: bool, silu_and_mul: bool = False):
+    """fused_add_rms_norm(g, residual) followed by gptq_marlin_gemm[_silu_and_mul] on the normed rows - LlamaDecoderLayer's
+    post_attention_layernorm + gate_up_proj + act, or the next layer's input_layernorm + qkv_proj (models/llama.py:205-230).
+    Returns (result, residual): result is the DeferredGemm of gptq_marlin_gemm_deferred (silu_and_mul=False) or the activation
+    tensor [size_m, size_n / 2]; residual is the tensor that now holds the updated residual stream.
+    At batch <= 4 (fp16, int4 without act-order, the decode kernel's shapes: nmx_gptq_marlin_gemm_norm_supported) this is ONE
+    launch - every workgroup of the GEMM computes the norm in its prologue while its first weight loads are in flight, and the
+    residual goes to a NEW tensor; otherwise the two ops run one after the other and the residual is updated in place. The
+    results are bit-identical either way (tests/test_fused_gpu.py)."""
+    _dev(residual)
+    has_idx = g_idx is not None and g_idx.numel() > 0
+    fused = (g.splits >= 2 and g.sa is None and not has_idx and residual.dtype == torch.float16 and residual.is_contiguous()
+             and tuple(residual.shape) == (size_m, size_k) and _lib.lib().nmx_gptq_marlin_gemm_norm_supported(
+                 c_int(size_m), c_int(size_n), c_int(size_k), c_int(b_scales.shape[0]), c_int(num_bits), c_int(_dt(residual)),
+                 c_int(int(silu_and_mul))))
+    if not fused:
+        h = fused_add_rms_norm_splitk(g, residual, norm_weight, epsilon)
+        if silu_and_mul:
+            return gptq_marlin_gemm_silu_and_mul(h, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, size_m, size_n, size_k,
+                                                 is_k_full), residual
+        return gptq_marlin_gemm_deferred(h, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, size_m, size_n, size_k,
+                                         is_k_full), residual
+    res_out = torch.empty_like(residual)
+    c = torch.empty((size_m, size_n), dtype=residual.dtype, device=residual.device)
+    act = torch.empty((size_m, size_n // 2), dtype=residual.dtype, device=residual.device) if silu_and_mul else None
+    scratch = _marlin_scratch(residual, size_m, size_n, size_k)
+    splits = c_int(1)
+    _lib.check(_lib.lib().nmx_gptq_marlin_gemm_norm(
+        _p(g.partial), c_int(g.coded), _p(residual), _p(res_out), _p(norm_weight), c_f(epsilon), _p(b_q_weight), _p(b_scales), _p(c),
+        _p(act), c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n), c_int(size_k),
+        c_int(num_bits), c_int(b_scales.shape[0]), c_int(_dt(residual)), ctypes.byref(splits), _stream(residual)))
+    g.splits = 1  # consumed (g.out was not written: the sum only ever existed inside the GEMM's prologue)
+    if silu_and_mul:
+        return act, res_out
+    if (splits.value & 0xff) > 1:
+        partial, n = _slabs(scratch, splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, n), res_out
+    return DeferredGemm(c, None, 1), res_out
+
+
 def fused_add_rms_norm_splitk(g: DeferredGemm, residual: torch.Tensor, weight: torch.Tensor, epsilon: float,
                               want_absmax: bool = False):
     """fused_add_rms_norm(g.out, residual, ...) on the deferred GEMM output; returns the normed tensor (g.out's storage), or

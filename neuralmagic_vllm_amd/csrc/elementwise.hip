@@ -7,21 +7,6 @@
 
 namespace {
 
-__device__ __forceinline__ float block_sum(float v, float* smem) {
-  v = wave_reduce_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nw = (blockDim.x + 63) >> 6;
-  if (lane == 0) smem[wave] = v;
-  __syncthreads();
-  float t = (threadIdx.x < nw) ? smem[threadIdx.x] : 0.f;
-  if (wave == 0) {
-    t = wave_reduce_sum(t);
-    if (lane == 0) smem[16] = t;
-  }
-  __syncthreads();
-  return smem[16];
-}
-
 // max over the workgroup, written by thread 0 (dynamic fp8 quantisation: the producer of an activation leaves one |max|
 // per workgroup for nmx_scaled_fp8_quant_partials instead of a separate absmax launch re-reading the tensor)
 __device__ __forceinline__ void block_max_store(float v, float* smem, float* dst) {
@@ -303,53 +288,7 @@ int launch_act(void* out, const void* in, int num_tokens, int d, int act, bool g
 }
 
 
-// ---- consumers of DEFERRED split-K partial sums ---------------------------------------------------------------------
-// A Marlin-family GEMM that splits K across workgroups leaves fp32 slabs partial[s][row][col]; instead of a reduce launch
-// (read the slabs, write fp16, then the next element-wise op reads that again) the op that consumes the GEMM output sums
-// them while loading its row: one dependent launch and one fp16 round trip less per GEMM. The sum runs in the order of
-// splitk_reduce_kernel (s = 0, 1, ...) and is rounded to scalar_t before any further arithmetic, so every result is
-// bit-identical to the unfused op sequence.
-// sa / sb (both or neither): per-tensor scales of a deferred fp8 scaled_mm, applied as its epilogue does - sa * (sb * sum)
-// (quant_ops.hip mm_epilogue4) - before the rounding to scalar_t.
-template <typename T>
-__device__ __forceinline__ void sum_partials8(const float* __restrict__ partial, int splits, int64_t slab, int64_t off, T (&e)[8],
-                                              const float* __restrict__ sa = nullptr, const float* __restrict__ sb = nullptr) {
-  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-  const int ns = NMX_SPLITK_COUNT(splits);
-  if (splits & NMX_SPLITK_F16) {  // (uniform) fp16 slabs: 16 bytes = the 8 elements
-    const f16* ph = reinterpret_cast<const f16*>(partial);
-    for (int sidx = 0; sidx < ns; ++sidx) {
-      union { u32x4 u; f16 h[8]; } v;
-      v.u = *reinterpret_cast<const u32x4*>(ph + sidx * slab + off);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a0[j] += (float)v.h[j];
-        a1[j] += (float)v.h[4 + j];
-      }
-    }
-  } else {
-    for (int sidx = 0; sidx < ns; ++sidx) {
-      a0 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off);
-      a1 += *reinterpret_cast<const f32x4*>(partial + sidx * slab + off + 4);
-    }
-  }
-  if (sa != nullptr) {
-    const float va = sa[0], vb = sb[0];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float x0 = va * (vb * a0[j]), x1 = va * (vb * a1[j]);
-      asm volatile("" : "+v"(x0), "+v"(x1));  // fp32 rounding step of its own, as in mm_epilogue4 (no fusion with the conversion)
-      a0[j] = x0;
-      a1[j] = x1;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    e[j] = Scalar<T>::from_f32(a0[j]);
-    e[4 + j] = Scalar<T>::from_f32(a1[j]);
-  }
-}
-
+// (block_sum / sum_partials8: nmx_common.h - marlin_decode_kernel<NORM> computes the same norm in its prologue)
 // fused_add_rms_norm on x = round(sum_s partial[s]): residual += x; out = norm(residual) * weight (layernorm_kernels.cu:258-291)
 template <typename T, int VPT>
 __global__ void rms_norm_splitk_kernel(T* __restrict__ out, const float* __restrict__ partial, int splits, const float* __restrict__ sa,

@@ -8,7 +8,7 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
                   const int32_t* perm, void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes,
                   int size_m, int size_n, int size_k, int kind, int num_groups, int is_k_full, int dtype,
                   hipStream_t stream, int defer_reduce = 0, int* splits_out = nullptr, void* act_out = nullptr,
-                  int* act_done = nullptr) {
+                  int* act_done = nullptr, const GemmParams* norm = nullptr) {
   // checks mirror gptq_marlin.cu:1741-1843
   NMX_CHECK(size_k % 16 == 0, NMX_ERR_INVALID_ARG, "size_k = %d is not divisible by tile_size = 16", size_k);
   NMX_CHECK(size_n % 64 == 0, NMX_ERR_INVALID_ARG, "size_n = %d is not divisible by min_thread_n = 64", size_n);
@@ -23,6 +23,10 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.k_splits = 1; p.slow_act_order = 0;
   p.defer_reduce = defer_reduce;
   p.act_out = act_out;
+  if (norm != nullptr) {
+    p.norm_partial = norm->norm_partial; p.norm_splits = norm->norm_splits; p.norm_res_in = norm->norm_res_in;
+    p.norm_res_out = norm->norm_res_out; p.norm_weight = norm->norm_weight; p.norm_eps = norm->norm_eps;
+  }
   if (splits_out != nullptr) *splits_out = 1;
   if (act_done != nullptr) *act_done = 0;
   if (has_act_order) {
@@ -42,6 +46,9 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   }
   if (num_groups > 1 && !p.slow_act_order)
     NMX_CHECK(p.group_size % 32 == 0, NMX_ERR_UNSUPPORTED, "group_size = %d must be a multiple of 32", p.group_size);
+  NMX_CHECK(norm == nullptr || (kind == W_INT4 && !has_act_order && dtype == NMX_F16 &&
+                                decode_norm_supported(size_m, size_n, size_k, num_groups, act_out != nullptr)),
+            NMX_ERR_UNSUPPORTED, "norm-fused gptq_marlin_gemm: fp16, int4 without act-order, shapes of nmx_gptq_marlin_gemm_norm_supported");
   NMX_CHECK(((uintptr_t)a % 16 == 0) && ((uintptr_t)b_q_weight % 16 == 0) && ((uintptr_t)b_scales % 16 == 0) &&
                 ((uintptr_t)c % 8 == 0) && size_k % 8 == 0,
             NMX_ERR_INVALID_ARG, "marlin gemm: operands must be 16-byte aligned");
@@ -181,4 +188,40 @@ extern "C" int nmx_fp8_marlin_gemm(const void* a, const int32_t* b_q_weight, con
   NMX_CHECK(num_bits == 8, NMX_ERR_INVALID_ARG, "num_bits must be 8 for fp8 marlin. Got = %d", num_bits);
   return marlin_common(a, b_q_weight, b_scales, nullptr, nullptr, c, workspace_numel, scratch, scratch_bytes, size_m,
                        size_n, size_k, W_FP8, 1, 1, dtype, (hipStream_t)stream);
+}
+
+// ---- fused_add_rms_norm + gptq_marlin_gemm as ONE launch at batch <= 4 (round 3, late; no reference counterpart: the reference
+// runs fused_add_rms_norm and the GEMM one after the other, models/llama.py:205-230). The GEMM's A operand is
+//   x = round(sum_s norm_partial[s]) + residual_in (rounded);  residual_out = x;  A = round(round(x * rsqrt(mean x^2 + eps)) * weight)
+// i.e. nmx_fused_add_rms_norm_splitk's arithmetic thread for thread, computed in the prologue of every workgroup of
+// marlin_decode_kernel while its first weight loads are in flight - one dependent launch less per norm. residual_out must not
+// alias residual_in. act_out == NULL: the GEMM as nmx_gptq_marlin_gemm_deferred leaves it (c or K-split slabs + *splits_out);
+// act_out != NULL: silu_and_mul of the result as nmx_gptq_marlin_gemm_silu_and_mul writes it. Results are bit-identical to the
+// unfused sequence. Ask nmx_gptq_marlin_gemm_norm_supported() first: other shapes return NMX_ERR_UNSUPPORTED.
+extern "C" int nmx_gptq_marlin_gemm_norm_supported(int size_m, int size_n, int size_k, int num_groups, int num_bits, int dtype,
+                                                   int with_act) {
+  return num_bits == 4 && dtype == NMX_F16 && decode_norm_supported(size_m, size_n, size_k, num_groups, with_act != 0) ? 1 : 0;
+}
+
+extern "C" int nmx_gptq_marlin_gemm_norm(const float* norm_partial, int norm_splits, const void* residual_in, void* residual_out,
+                                         const void* norm_weight, float epsilon, const int32_t* b_q_weight, const void* b_scales,
+                                         void* c, void* act_out, int64_t workspace_numel, void* scratch, int64_t scratch_bytes,
+                                         int size_m, int size_n, int size_k, int num_bits, int num_groups, int dtype, int* splits_out,
+                                         nmx_stream_t stream) {
+  NMX_CHECK(num_bits == 4, NMX_ERR_UNSUPPORTED, "norm-fused gptq_marlin_gemm: num_bits must be 4. Got = %d", num_bits);
+  NMX_CHECK(norm_partial != nullptr && NMX_SPLITK_COUNT(norm_splits) >= 2 && residual_in != nullptr && residual_out != nullptr &&
+                residual_in != residual_out && norm_weight != nullptr && splits_out != nullptr,
+            NMX_ERR_INVALID_ARG, "norm-fused gptq_marlin_gemm: >= 2 producer slabs, distinct residual buffers, weight, splits_out");
+  NMX_CHECK((((uintptr_t)norm_partial | (uintptr_t)residual_in | (uintptr_t)residual_out | (uintptr_t)norm_weight) % 16) == 0,
+            NMX_ERR_INVALID_ARG, "norm-fused gptq_marlin_gemm: operands must be 16-byte aligned");
+  GemmParams n;
+  n.norm_partial = norm_partial; n.norm_splits = norm_splits; n.norm_res_in = residual_in; n.norm_res_out = residual_out;
+  n.norm_weight = norm_weight; n.norm_eps = epsilon;
+  int done = 0;
+  // (a: any valid 16-byte aligned pointer - the kernel never reads it)
+  const int rc = marlin_common(residual_in, b_q_weight, b_scales, nullptr, nullptr, c, workspace_numel, scratch, scratch_bytes, size_m,
+                               size_n, size_k, W_INT4, num_groups, 1, dtype, (hipStream_t)stream, 1, splits_out, act_out, &done, &n);
+  if (rc == NMX_OK && act_out != nullptr && !done && size_m > 0 && size_n > 0)
+    NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "norm-fused gate_up: the dispatch did not take the fused-activation shape");
+  return rc;
 }

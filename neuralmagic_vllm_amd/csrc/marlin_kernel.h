@@ -223,7 +223,25 @@ struct GemmParams {
                            // c[:, N/2:] here INSTEAD of c and the host sets act_done; every other path leaves it alone
   int act_done = 0;        // host side only
   int xcd_split = 1;       // marlin_gemm_kernel: 2 / 4 / 8 K splits are placed one per group of XCDs (NMX_GEMM_XCD_SPLIT=0: off)
+  // marlin_decode_kernel<NORM> (round 3, late): the A operand is fused_add_rms_norm of a deferred GEMM's K-split slabs,
+  // computed in every workgroup's prologue (a is unused): x = round(sum_s norm_partial[s]) + norm_res_in; A = norm(x) * norm_weight;
+  // workgroup (0, 0) also writes x to norm_res_out (a buffer of its own: other workgroups still read norm_res_in)
+  const float* norm_partial = nullptr;  // [norm_splits][M][K] fp32, or fp16 with NMX_SPLITK_F16 set in norm_splits
+  int norm_splits = 0;
+  const void* norm_res_in = nullptr;    // [M, K] scalar_t
+  void* norm_res_out = nullptr;         // [M, K] scalar_t
+  const void* norm_weight = nullptr;    // [K] scalar_t
+  float norm_eps = 0.f;
 };
+constexpr int kNormMaxRows = 4;         // rows the norm-fused kernel can take (every workgroup recomputes the norm of all rows)
+// threads / vectors per thread of rms_norm_splitk_kernel for a hidden size (elementwise.hip add_rms_norm_splitk_common): the
+// norm-fused GEMM prologue sums the squares over the same threads in the same order, so the two forms agree bit for bit
+inline __host__ __device__ int norm_threads(int hidden) {
+  const int nvec = hidden / 8;
+  int t = ((nvec + 63) / 64) * 64;
+  if (nvec > 256) t = ((nvec / 2 + 63) / 64) * 64;
+  return t < 1024 ? t : 1024;
+}
 
 // ---- the GEMM kernel -------------------------------------------------------------------------------------------
 // Workgroup = 4 waves. Wave w owns 64-column group (w % NG) of the workgroup's 64*NG columns and K-slice (w / NG) of
@@ -1186,8 +1204,9 @@ __device__ __forceinline__ u32x4 frag_transpose(u32x4 v) {
   return u32x4{p01[0], p01[1], p23[0], p23[1]};
 }
 
-template <typename scalar_t, int MT, int NW, bool GROUPED, bool WS>
+template <typename scalar_t, int MT, int NW, bool GROUPED, bool WS, bool NORM = false>
 __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_kernel(const GemmParams p) {
+  static_assert(!NORM || MT == 1, "the norm-fused form takes one 16-row tile");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15, c8 = li & 7, hi = li >> 3;
@@ -1242,14 +1261,25 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
     u32x2 s[NS > 0 ? NS : 1];
   };
   // loads of one 32-k step / of the scale rows of unit u (past the slice: the last unit again, never consumed)
-  auto load_step = [&](int u, int ks, Unit& U) {
+  // NORM: the normalised rows live in LDS behind the reduction image - row r at r * XS (XS = 2 K + 64: four rows land in
+  // different 64-byte bank quarters), row M is all zeros and serves the tile's unused rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int XS = 2 * K + 64;
+  char* const xl = smem + NW * MT * 4096;
+  const char* const xl_lane = xl + min(li, M) * XS + 16 * g;
+  // WQ / WA: the weight-side (vector-memory) and the activation-side half of a step; the NORM prologue issues them apart
+  auto load_step = [&](int u, int ks, Unit& U, bool WQ = true, bool WA = true) {
     u = min(u, total_units - 1);
     // aux 2 = non-temporal: the weights are read once (this kernel is used with one row block; a constant, because a
     // branch around the load halves the wait counts hipcc can prove)
-    U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, (u * 8 + 2 * ks) * row_bytes, NMX_W_NT ? 2 : 0);
+    if (WQ) U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, (u * 8 + 2 * ks) * row_bytes, NMX_W_NT ? 2 : 0);
+    if constexpr (NORM) {
+      if (WA) U.a[ks][0] = *reinterpret_cast<const u32x4*>(xl_lane + (u * 128 + ks * 32) * 2);
+    } else {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      U.a[ks][mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], (u * 128 + ks * 32) * 2, 0);
+      for (int mt = 0; mt < MT; ++mt)
+        U.a[ks][mt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[mt], (u * 128 + ks * 32) * 2, 0);
+    }
     // pin the issue order: the prologue must queue the loads exactly as the loop does, or the (merged) wait counts
     // at the loop head degrade to those of the worse of the two orders
     __builtin_amdgcn_sched_barrier(0);
@@ -1263,11 +1293,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto load_unit = [&](int u, Unit& U) {  // same order as compute_unit re-issues them
-    if constexpr (WSCALE) load_scales(u, U);
+  auto load_unit = [&](int u, Unit& U, bool WQ = true, bool WA = true) {  // same order as compute_unit re-issues them
+    if constexpr (WSCALE) { if (WQ) load_scales(u, U); }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) load_step(u, ks, U);
-    if constexpr (!WSCALE) load_scales(u, U);
+    for (int ks = 0; ks < 4; ++ks) load_step(u, ks, U, WQ, WA);
+    if constexpr (!WSCALE) { if (WQ) load_scales(u, U); }
   };
 
   f32x4 acc[MT][4];
@@ -1342,10 +1372,89 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
     }
   };
 
+  Unit ua, ub;
+  if constexpr (NORM) {
+    // ---- the A operand: fused_add_rms_norm of the producer GEMM's K-split slabs, the arithmetic of rms_norm_splitk_kernel
+    //      (elementwise.hip) thread for thread - its NT threads sum the squares of the same elements in the same order ----
+    __shared__ float nsm[17];
+    const int nvec = K / 8, NT = norm_threads(K);
+    const int64_t slab = (int64_t)M * K;
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+    const scalar_t* res_in = reinterpret_cast<const scalar_t*>(p.norm_res_in);
+    scalar_t* res_out = reinterpret_cast<scalar_t*>(p.norm_res_out);
+    union V { u32x4 u; scalar_t e[8]; };
+    V x[2], wv[2];
+    const int tid = threadIdx.x;
+    auto nload = [&](int m) {  // x = round(sum of the slabs) + residual, rounded: row m, this thread's (up to) two vectors
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = tid + k * NT;
+        if (tid < NT && v < nvec) {
+          sum_partials8<scalar_t>(p.norm_partial, p.norm_splits, slab, (int64_t)m * K + v * 8, x[k].e);
+          V r;
+          r.u = *reinterpret_cast<const u32x4*>(res_in + (int64_t)m * K + v * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[k].e[j] = Scalar<scalar_t>::from_f32(Scalar<scalar_t>::to_f32(x[k].e[j]) + Scalar<scalar_t>::to_f32(r.e[j]));
+        }
+      }
+    };
+    auto nmath = [&](int m) {
+      float var = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = tid + k * NT;
+        if (tid < NT && v < nvec) {
+          if (writer) *reinterpret_cast<u32x4*>(res_out + (int64_t)m * K + v * 8) = x[k].u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float f = Scalar<scalar_t>::to_f32(x[k].e[j]);
+            var += f * f;
+          }
+        }
+      }
+      var = block_sum(var, nsm);
+      const float sc = rsqrtf(var / (float)K + p.norm_eps);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = tid + k * NT;
+        if (tid < NT && v < nvec) {
+          V o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = rnd_mul<scalar_t>(Scalar<scalar_t>::from_f32(Scalar<scalar_t>::to_f32(x[k].e[j]) * sc), wv[k].e[j]);
+          *reinterpret_cast<u32x4*>(xl + m * XS + v * 16) = o.u;
+        }
+      }
+    };
+    // the weight stream of the first two units goes out FIRST (it does not depend on the norm): the norm's own loads queue
+    // behind it and one wait covers both - issued the other way round, the sum of the slabs (which consumes its loads at
+    // once) put a whole memory round trip in front of the first weight request
+    if (u0 < u1) {
+      load_unit(u0, ua, true, false);
+      load_unit(u0 + 1, ub, true, false);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int v = tid + k * NT;
+      if (tid < NT && v < nvec) wv[k].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const scalar_t*>(p.norm_weight) + v * 8);
+    }
+    nload(0);
+    for (int e = tid; e < (2 * K) / 16; e += 64 * NW) *reinterpret_cast<u32x4*>(xl + M * XS + e * 16) = u32x4{0, 0, 0, 0};
+    nmath(0);
+    for (int m = 1; m < M; ++m) {
+      nload(m);
+      nmath(m);
+    }
+    __syncthreads();
+    if (u0 < u1) {
+      load_unit(u0, ua, false, true);
+      load_unit(u0 + 1, ub, false, true);
+    }
+  }
   if (u0 < u1) {
-    Unit ua, ub;
-    load_unit(u0, ua);
-    load_unit(u0 + 1, ub);
+    if constexpr (!NORM) {
+      load_unit(u0, ua);
+      load_unit(u0 + 1, ub);
+    }
     // always whole pairs, branch-free: an odd last unit computes on the (reloaded) final unit and is dropped through
     // its weight 0. A conditional second half would make the wait counts at the loop head cover the path that skipped
     // it (half the ring); a peeled tail costs a third copy of the body and its registers.
@@ -1356,7 +1465,6 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
   }
 
   // ---- sum the NW K slices through LDS: thread e < 256 MT owns float4 e of the workgroup's [MT][4][64] tile image ----
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* red = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -1705,13 +1813,34 @@ inline DecodeCfg pick_decode_cfg(int M, int N, int K) {
   return c;
 }
 
-template <typename scalar_t, int MT, int NW, bool WS>
+// Shapes the norm-fused form (marlin_decode_kernel<NORM>) serves: fp16, plain int4 layout (the caller knows), at most
+// kNormMaxRows rows, the decode kernel's 4-wave shape (with_act: its unsplit gate | up form), and a hidden size whose
+// rms_norm_splitk_kernel thread count fits the workgroup (bit identity with the unfused sequence)
+inline bool decode_norm_supported(int M, int N, int K, int num_groups, bool with_act) {
+  // Rows served by default: ONE. Every workgroup pulls a row's slabs + residual through its CU (80 - 150 KB at ~64 B/clk:
+  // 0.6 - 1.1 us per row), which the saved launch (~3.7 us) pays for once, not two to four times - measured on the decode
+  // step: batch 1 2.31 -> 2.19 ms, batch 2 2.34 -> 2.42, batch 4 2.38 -> 2.84 (gpurun_out/norm_ab.log). NMX_GEMM_NORM_ROWS
+  // raises the limit (tests: the multi-row prologue stays covered).
+  int max_rows = 1;
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_NORM_ROWS)) max_rows = std::min(std::max(atoi(e), 0), kNormMaxRows);
+  if (M < 1 || M > max_rows || K % 128 != 0 || N % 64 != 0 || K / 8 > 2 * 1024) return false;
+  if (!(num_groups == 1 || (K / num_groups) % 128 == 0)) return false;
+  const DecodeCfg c = pick_decode_cfg(M, N, K);
+  if (c.nw != 4 || c.mt != 1) return false;
+  const int nt = norm_threads(K);
+  if ((K / 8 + nt - 1) / nt > 2) return false;
+  if (with_act) return c.splits == 1 && N % 128 == 0 && nt <= 512;
+  return nt <= 256;
+}
+
+template <typename scalar_t, int MT, int NW, bool WS, bool NORM = false>
 int launch_decode_cfg(const GemmParams& p, hipStream_t stream) {
-  const size_t smem = (size_t)NW * MT * 4096;
+  // NORM: + the normalised rows and one zero row (marlin_decode_kernel: XS = 2 K + 64 bytes per row)
+  const size_t smem = (size_t)NW * MT * 4096 + (NORM ? (size_t)(p.M + 1) * (2 * p.K + 64) : 0);
   dim3 grid(p.act_out != nullptr ? p.N / 128 : p.N / 64, p.k_splits, ceil_div(p.M, 16 * MT));
 #define NMX_LAUNCH_DECODE(GROUPED_)                                                                                  \
   {                                                                                                                  \
-    auto kern = marlin_decode_kernel<scalar_t, MT, NW, GROUPED_, WS>;                                                    \
+    auto kern = marlin_decode_kernel<scalar_t, MT, NW, GROUPED_, WS, NORM>;                                              \
     if (smem > 64 * 1024)                                                                                            \
       NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                   (int)smem));                                                                       \
@@ -1740,6 +1869,20 @@ int launch_decode(GemmParams& p, const DecodeCfg& cfg, void* scratch, int64_t sc
   const bool fuse = p.act_out != nullptr && p.k_splits == 1 && cfg.nw == 4 && cfg.mt == 1 && p.N % 128 == 0;
   void* const act_out = p.act_out;
   p.act_out = nullptr;  // the kernels below read it as "fused mode"
+  if (p.norm_partial != nullptr) {
+    // norm-fused A operand: the two shapes the batch <= 4 decode step uses (callers ask decode_norm_supported() first)
+    if constexpr (__is_same(scalar_t, f16)) {
+      if (fuse) {
+        p.act_out = act_out;
+        rc = ws ? launch_decode_cfg<scalar_t, 1, 8, true, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 8, false, true>(p, stream);
+        p.act_done = 1;
+        return rc;
+      }
+      if (cfg.mt == 1 && cfg.nw == 4 && act_out == nullptr && (p.k_splits == 1 || p.defer_reduce))
+        return ws ? launch_decode_cfg<scalar_t, 1, 4, true, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 4, false, true>(p, stream);
+    }
+    NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "norm-fused gptq_marlin_gemm: shape not served (M = %d, N = %d, K = %d)", p.M, p.N, p.K);
+  }
   if (fuse) {
     p.act_out = act_out;
     rc = ws ? launch_decode_cfg<scalar_t, 1, 8, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 8, false>(p, stream);

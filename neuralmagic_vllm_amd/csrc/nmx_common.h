@@ -43,7 +43,7 @@ void nmx_set_error(const char* fmt, ...);
 enum NmxTune {
   NMX_TUNE_GEMM_CFG = 0, NMX_TUNE_GEMM_LEAN, NMX_TUNE_GEMM_LARGE, NMX_TUNE_GEMM_LARGE_NGRP, NMX_TUNE_GEMM_WIDE,
   NMX_TUNE_ATTN_NW, NMX_TUNE_PREFILL_GQ, NMX_TUNE_MM_NO_LDS, NMX_TUNE_MM_NT, NMX_TUNE_AWQ_NO_RING, NMX_TUNE_GPTQ_NO_RING,
-  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_SLAB_F32, NMX_TUNE_ATTN_PART, NMX_TUNE_COUNT
+  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_SLAB_F32, NMX_TUNE_ATTN_PART, NMX_TUNE_GEMM_NORM_ROWS, NMX_TUNE_COUNT
 };
 __attribute__((visibility("hidden"))) const char* nmx_tune(int id);  // value, or nullptr when unset
 
@@ -125,6 +125,93 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
+
+// sum over the workgroup (two barriers; smem: 17 floats); waves that pass 0 do not change the result
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  float t = (threadIdx.x < nw) ? smem[threadIdx.x] : 0.f;
+  if (wave == 0) {
+    t = wave_reduce_sum(t);
+    if (lane == 0) smem[16] = t;
+  }
+  __syncthreads();
+  return smem[16];
+}
+
+
+// ---- consumers of DEFERRED split-K partial sums ---------------------------------------------------------------------
+// A Marlin-family GEMM that splits K across workgroups leaves fp32 slabs partial[s][row][col]; instead of a reduce launch
+// (read the slabs, write fp16, then the next element-wise op reads that again) the op that consumes the GEMM output sums
+// them while loading its row: one dependent launch and one fp16 round trip less per GEMM. The sum runs in the order of
+// splitk_reduce_kernel (s = 0, 1, ...) and is rounded to scalar_t before any further arithmetic, so every result is
+// bit-identical to the unfused op sequence.
+// sa / sb (both or neither): per-tensor scales of a deferred fp8 scaled_mm, applied as its epilogue does - sa * (sb * sum)
+// (quant_ops.hip mm_epilogue4) - before the rounding to scalar_t.
+template <typename T>
+__device__ __forceinline__ void sum_partials8(const float* __restrict__ partial, int splits, int64_t slab, int64_t off, T (&e)[8],
+                                              const float* __restrict__ sa = nullptr, const float* __restrict__ sb = nullptr) {
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  const int ns = NMX_SPLITK_COUNT(splits);
+  // The slabs are fetched in batches of up to 8 loads issued back to back (round 3, late: with one load per loop iteration
+  // every slab cost a full memory round trip - a 14-slab down_proj row took ~14 of them); the additions keep the order
+  // s = 0, 1, ... of splitk_reduce_kernel, so nothing changes in the result. Slots past the count re-read the last slab.
+  constexpr int BATCH = 8;
+  if (splits & NMX_SPLITK_F16) {  // (uniform) fp16 slabs: 16 bytes = the 8 elements
+    const f16* ph = reinterpret_cast<const f16*>(partial);
+    for (int s0 = 0; s0 < ns; s0 += BATCH) {
+      union { u32x4 u; f16 h[8]; } v[BATCH];
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) v[i].u = *reinterpret_cast<const u32x4*>(ph + min(s0 + i, ns - 1) * slab + off);
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        if (s0 + i < ns) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            a0[j] += (float)v[i].h[j];
+            a1[j] += (float)v[i].h[4 + j];
+          }
+        }
+      }
+    }
+  } else {
+    for (int s0 = 0; s0 < ns; s0 += BATCH) {
+      f32x4 t0[BATCH], t1[BATCH];
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        const float* src = partial + min(s0 + i, ns - 1) * slab + off;
+        t0[i] = *reinterpret_cast<const f32x4*>(src);
+        t1[i] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        if (s0 + i < ns) {
+          a0 += t0[i];
+          a1 += t1[i];
+        }
+      }
+    }
+  }
+  if (sa != nullptr) {
+    const float va = sa[0], vb = sb[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0 = va * (vb * a0[j]), x1 = va * (vb * a1[j]);
+      asm volatile("" : "+v"(x0), "+v"(x1));  // fp32 rounding step of its own, as in mm_epilogue4 (no fusion with the conversion)
+      a0[j] = x0;
+      a1[j] = x1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    e[j] = Scalar<T>::from_f32(a0[j]);
+    e[4 + j] = Scalar<T>::from_f32(a1[j]);
+  }
+}
+
 
 static inline int nmx_dtype_size(int dt) { return dt == NMX_F32 ? 4 : 2; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -307,3 +307,63 @@ def test_deferred_fp8_scaled_mm_consumers(ops, M, K, N):
     torch.cuda.synchronize()
     assert torch.equal(_bits(out_a), _bits(out_b))
     assert torch.equal(amax2, out_a.float().abs().amax(dim=1))
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("producer", ["o_proj", "down_proj"])
+@pytest.mark.parametrize("consumer", ["qkv", "gate_up_act", "o_like"])
+@pytest.mark.parametrize("rows", [None, "4"])
+def test_norm_fused_gemm(ops, tune, M, producer, consumer, rows):
+    """Round 3 (late): fused_add_rms_norm + gptq_marlin_gemm[_silu_and_mul] as ONE launch at batch <= 4
+    (fused_add_rms_norm_gptq_marlin_gemm -> nmx_gptq_marlin_gemm_norm: the norm runs in the GEMM's prologue). Producers: the
+    deferred K-split slabs of o_proj (4096 -> 4096) and down_proj (14336 -> 4096); consumers: qkv (deferred slabs again),
+    gate_up + silu_and_mul, and a 4096 x 4096 matrix. Bit-identical to fused_add_rms_norm_splitk followed by the GEMM op -
+    output, residual and the deferred slabs after materialize() -, the oracle's unfused norm on the reduced producer output
+    bounds the A operand. By default ONE row is served (more rows cost more than the launch saves); NMX_GEMM_NORM_ROWS=4
+    opens the multi-row prologue; rows beyond the limit take the two-launch route through the same op (in-place residual)."""
+    tune(NMX_GEMM_NORM_ROWS=rows)
+    seed_all(M)
+    Kp = 4096 if producer == "o_proj" else 14336
+    H = 4096
+    qp, sp = _weights(Kp, H, 3)
+    a = torch.randn(M, Kp, dtype=torch.float16, device=DEV)
+    N = {"qkv": 6144, "gate_up_act": 28672, "o_like": 4096}[consumer]
+    act = consumer == "gate_up_act"
+    qc, sc = _weights(H, N, 4)
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    wsp = torch.zeros(max(N, H) // 64 * 16, dtype=torch.int32, device=DEV)
+    res0 = torch.randn(M, H, dtype=torch.float16, device=DEV)
+    w = (torch.rand(H, device=DEV) + 0.5).half()
+
+    # the unfused sequence
+    g1 = ops.gptq_marlin_gemm_deferred(a, qp, sp, e, e, wsp, 4, M, H, Kp, True)
+    assert g1.splits > 1
+    res_a = res0.clone()
+    h = ops.fused_add_rms_norm_splitk(g1, res_a, w, 1e-5).clone()
+    if act:
+        want = ops.gptq_marlin_gemm_silu_and_mul(h, qc, sc, e, e, wsp, 4, M, N, H, True)
+    else:
+        want = ops.gptq_marlin_gemm(h, qc, sc, e, e, wsp, 4, M, N, H, True)
+
+    # the fused op on a fresh deferred producer
+    g2 = ops.gptq_marlin_gemm_deferred(a, qp, sp, e, e, wsp, 4, M, H, Kp, True)
+    res_b = res0.clone()
+    got, res_new = ops.fused_add_rms_norm_gptq_marlin_gemm(g2, res_b, w, 1e-5, qc, sc, e, e, wsp, 4, M, N, H, True,
+                                                           silu_and_mul=act)
+    torch.cuda.synchronize()
+    from neuralmagic_vllm_amd import _lib
+    served = bool(_lib.lib().nmx_gptq_marlin_gemm_norm_supported(M, N, H, H // 128, 4, 1, int(act)))
+    assert served == (M <= (4 if rows else 1))
+    if served:
+        assert res_new.data_ptr() != res_b.data_ptr() and torch.equal(_bits(res_b), _bits(res0))  # the input residual is only read
+    else:
+        assert res_new.data_ptr() == res_b.data_ptr()
+    assert torch.equal(_bits(res_new), _bits(res_a))
+    out = got if act else got.materialize()
+    assert torch.equal(_bits(out), _bits(want))
+    assert g2.splits == 1  # consumed
+    # the oracle's unfused norm on the reduced producer output, then its GEMM slice on a few columns
+    x_o, r_o = ops.gptq_marlin_gemm(a, qp, sp, e, e, wsp, 4, M, H, Kp, True).cpu(), res0.cpu()
+    oracle.fused_add_rms_norm(x_o, r_o, w.cpu(), 1e-5)
+    assert torch.equal(_bits(res_new.cpu()), _bits(r_o))
+    torch.testing.assert_close(h.cpu().float(), x_o.float(), atol=4e-3, rtol=4e-3)
