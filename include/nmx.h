@@ -113,7 +113,11 @@ int nmx_paged_attention_v2_ps(void* out, float* absmax, float* exp_sums, float* 
                               float scale, const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
                               int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
                               int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
-                              int partition_size, nmx_stream_t stream);
+                              int partition_size, int* counters, nmx_stream_t stream);
+/* counters (may be NULL): int32 [nmx_paged_attention_counters_numel()], all zero before the call (and all zero again after it),
+ * not shared with another launch in flight: the last partition workgroup to finish a (sequence, kv head) then reduces the
+ * partitions itself and no reduce kernel is launched (fp16 / bf16 queries; same output bits). */
+int64_t nmx_paged_attention_counters_numel(int num_seqs, int num_heads, int num_kv_heads);
 
 /* ------------------------------------------------------------------------------------------------------------
  * KV-cache ops. Replace csrc/cache_kernels.cu (schema csrc/torch_bindings.cpp:207-244, csrc/cache.h:8-32).

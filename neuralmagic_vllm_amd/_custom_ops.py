@@ -6,6 +6,7 @@ strides and the current HIP stream, then calls the C-ABI (``include/nmx.h``); no
 host, and there is no fallback path.
 """
 import ctypes
+import os
 from typing import List, Optional, Tuple, Type
 
 import torch
@@ -217,7 +218,27 @@ def _v2_fine_partition(query, num_kv_heads, max_seq_len):
     parts = (max_seq_len + ps - 1) // ps
     tmp = torch.empty(num_seqs, num_heads, parts, head_size, dtype=query.dtype, device=query.device)
     sums = torch.empty(2, num_seqs, num_heads, parts, dtype=torch.float32, device=query.device)
-    return ps, (sums[0], sums[1], tmp)
+    return ps, (sums[0], sums[1], tmp, _v2_counters(query, num_kv_heads))
+
+
+_V2_COUNTERS = {}  # (device index, stream handle) -> int32 zeros; launches on one stream run one after the other
+
+
+def _v2_counters(query, num_kv_heads):
+    """Arrival counters of the in-kernel v2 reduce: all zero between launches (the kernel puts them back), one tensor per
+    (device, stream) so that two launches in flight never share one. OFF unless NMX_ATTN_INKERNEL_REDUCE=1 (environment, read
+    per call by this wrapper only): measured level with the reduce launch it saves (batch 1: 9.2 vs 9.6 us per attention call,
+    batch 4 / 8 equal - the drain + ticket + agent-scope loads cost what the launch boundary costs), and its cross-workgroup
+    hand-off rests on measured, not architecturally guaranteed, cache behaviour (MI355X_MICROARCH.md, valid forms)."""
+    if os.environ.get("NMX_ATTN_INKERNEL_REDUCE", "0") != "1" or query.dtype == torch.float32:
+        return None
+    n = int(_lib.lib().nmx_paged_attention_counters_numel(c_int(query.shape[0]), c_int(query.shape[1]), c_int(num_kv_heads)))
+    key = (query.device.index, int(_raw_stream(_raw_device())))
+    buf = _V2_COUNTERS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n, 1024), dtype=torch.int32, device=query.device)
+        _V2_COUNTERS[key] = buf
+    return buf
 
 
 def paged_attention_v1(
@@ -274,7 +295,7 @@ def paged_attention_v2(
         _attn_common(_lib.lib().nmx_paged_attention_v2_ps, (_p(out), _p(None), _p(own[0]), _p(own[1]), _p(own[2])), query, key_cache,
                      value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
                      kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
-                     blocksparse_head_sliding_step, tail_args=(c_int(ps), ))
+                     blocksparse_head_sliding_step, tail_args=(c_int(ps), _p(own[3])))
         return
     _attn_common(_lib.lib().nmx_paged_attention_v2, (_p(out), _p(exp_sum), _p(max_logits), _p(tmp_out)), query,
                  key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
@@ -307,7 +328,7 @@ def paged_attention_v2_absmax(out, exp_sum, max_logits, tmp_out, query, key_cach
         _attn_common(_lib.lib().nmx_paged_attention_v2_ps, (_p(out), _p(amax), _p(own[0]), _p(own[1]), _p(own[2])), query, key_cache,
                      value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
                      kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
-                     blocksparse_head_sliding_step, tail_args=(c_int(ps), ))
+                     blocksparse_head_sliding_step, tail_args=(c_int(ps), _p(own[3])))
         return amax
     _attn_common(_lib.lib().nmx_paged_attention_v2_absmax, (_p(out), _p(amax), _p(exp_sum), _p(max_logits), _p(tmp_out)), query,
                  key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,

@@ -42,6 +42,7 @@ constexpr int kTile = 32;            // tokens per wave iteration
 
 struct AttnParams {
   void* out;          // v1: [S, H, D]; v2: tmp_out [S, H, P, D]
+  void* final_out;    // v2 with the in-kernel reduce (counters != null): [S, H, D]
   float* exp_sums;    // v2: [S, H, P]
   float* max_logits;  // v2: [S, H, P]
   const void* q;
@@ -55,6 +56,7 @@ struct AttnParams {
   int num_heads, num_kv_heads, q_per_kv, q_tiles;
   int max_blocks_per_seq, block_size, bs_shift;
   int partitioned, max_num_partitions;
+  int* counters;      // v2, in-kernel reduce: [num_seqs][kv heads x q tiles] arrival counts, all zero before AND after a launch (or null)
   int part_size;      // tokens per partition (v2: 512 by contract; nmx_paged_attention_v2_ps: 64 .. 512, a multiple of 64)
   int sparse, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step;
   // optional (nmx_paged_attention_v1/v2_absmax): max |out| of what a workgroup (v1: one per kv head x q tile x sequence) / the
@@ -149,6 +151,114 @@ __device__ __forceinline__ u32x4 p_to_operand(u32x2 a, u32x2 b) {
     r[2 + d] = s2[1];
   }
   return r;
+}
+
+
+// ---- v2 reduce of one (sequence, head) by ONE wave: follows attention_kernels.cu:567-669. Shared by the reduce kernel and by
+// the in-kernel reduce of the last-arriving partition (below), so the two forms write the same bits. resc: np floats of LDS. ----
+// COHERENT: the partials were written by other workgroups of the SAME launch with write-through stores; they are read with
+// agent-scope (sc1) loads, which do not hit a stale line of this CU's L1 or this XCD's L2.
+template <bool COHERENT> __device__ __forceinline__ float ld_f32(const float* p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COHERENT, typename scalar_t> __device__ __forceinline__ scalar_t ld_elem(const scalar_t* p) {
+  if constexpr (COHERENT) {  // the aligned dword that holds the element
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint16_t h = (a & 2) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
+    return __builtin_bit_cast(scalar_t, h);
+  } else {
+    return *p;
+  }
+}
+
+template <typename scalar_t, bool COHERENT = false>
+__device__ __forceinline__ void v2_reduce_head(scalar_t* __restrict__ o, const float* __restrict__ exp_sums,
+                                               const float* __restrict__ max_logits, const scalar_t* __restrict__ tp, int np,
+                                               int head_size, float* __restrict__ absmax_dst, float* resc, int lane) {
+  float amax = 0.f;
+  if (np <= 1) {
+    for (int i = lane; i < head_size; i += 64) {
+      const scalar_t v = ld_elem<COHERENT>(tp + i);
+      o[i] = v;
+      amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(v)));
+    }
+    if (absmax_dst != nullptr) {
+      amax = wave_reduce_max(amax);
+      if (lane == 0) *absmax_dst = amax;
+    }
+    return;
+  }
+  float m = -FLT_MAX;
+  for (int i = lane; i < np; i += 64) m = fmaxf(m, ld_f32<COHERENT>(max_logits + i));
+  m = wave_reduce_max(m);
+  float gsum = 0.f;
+  for (int i = lane; i < np; i += 64) {
+    const float r = ld_f32<COHERENT>(exp_sums + i) * __expf(ld_f32<COHERENT>(max_logits + i) - m);
+    resc[i] = r;
+    gsum += r;
+  }
+  gsum = wave_reduce_sum(gsum);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes before its reads (one wave: no s_barrier)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float inv = __fdividef(1.f, gsum + 1e-6f);
+  for (int d = lane; d < head_size; d += 64) {
+    float acc = 0.f;
+    // (the partitions' values in batches of 8 loads issued back to back - with one load per iteration every partition cost a
+    //  memory round trip; the additions keep the order j = 0, 1, ...)
+    for (int j0 = 0; j0 < np; j0 += 8) {
+      scalar_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ld_elem<COHERENT>(tp + (int64_t)min(j0 + i, np - 1) * head_size + d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (j0 + i < np) acc += Scalar<scalar_t>::to_f32(v[i]) * resc[j0 + i] * inv;
+    }
+    const scalar_t ov = Scalar<scalar_t>::from_f32(acc);
+    o[d] = ov;
+    amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(ov)));
+  }
+  if (absmax_dst != nullptr) {
+    amax = wave_reduce_max(amax);
+    if (lane == 0) *absmax_dst = amax;
+  }
+}
+
+// ---- v2 without a reduce launch (round 3, late): every partition workgroup of a (sequence, kv head, q tile) publishes its
+// partial results, then takes a ticket on that group's counter; the LAST one to arrive reduces the group's heads (one wave per
+// head, v2_reduce_head) and puts the counter back to zero. Nobody waits for anybody: a workgroup either finds it is last or
+// leaves. Visibility across CUs / XCDs (MI355X_MICROARCH.md, inter-workgroup visibility, the form without fences): EVERY
+// partial store is a write-through agent-scope store, drained (vmcnt(0)) before the workgroup's barrier and the ticket (an
+// agent-scope atomic); the last arriver reads EVERY partial with agent-scope loads. Called by all threads of the workgroup at the end of a partitioned launch; smem_f: NW * np floats, free to use. ----
+template <typename scalar_t, int NW>
+__device__ __forceinline__ void v2_last_arriver_reduce(const AttnParams& p, int seq, int kvh, int qt, int seq_len, int D,
+                                                       float* smem_f) {
+  __shared__ int s_last;
+  // The partial results went out as write-through (agent-scope) stores: drained here, they are in memory before the ticket.
+  // (An agent-scope release FENCE instead writes the whole L2's dirty lines back: measured 14.2 vs 9.4 us per attention call at
+  // batch 1 and 33.8 vs 10.8 at batch 4 - slower than the reduce launch it was meant to save.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // (also: everyone is done with the LDS images smem_f overlays)
+  const int np = (seq_len + p.part_size - 1) / p.part_size;
+  int* ctr = p.counters + (int64_t)seq * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == np - 1) ? 1 : 0;
+    if (old == np - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+  __syncthreads();
+  if (s_last == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = min(16, p.q_per_kv - qt * 16);  // heads of this q tile
+  for (int r = wave; r < rows; r += NW) {
+    const int head = kvh * p.q_per_kv + qt * 16 + r;
+    const int64_t pb = ((int64_t)seq * p.num_heads + head) * p.max_num_partitions;
+    v2_reduce_head<scalar_t, true>(reinterpret_cast<scalar_t*>(p.final_out) + ((int64_t)seq * p.num_heads + head) * D, p.exp_sums + pb,
+                             p.max_logits + pb, reinterpret_cast<const scalar_t*>(p.out) + pb * D, np, D,
+                             p.absmax != nullptr ? p.absmax + (int64_t)seq * p.num_heads + head : nullptr, smem_f + wave * np, lane);
+  }
 }
 
 template <typename scalar_t, int KV, int D, int NW>
@@ -418,8 +528,13 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
     const int64_t pidx = ((int64_t)seq * p.num_heads + chead) * p.max_num_partitions + part;
     outp = reinterpret_cast<scalar_t*>(p.out) + pidx * D;
     if ((t >> 4) == 0 && active) {
-      p.max_logits[pidx] = M;
-      p.exp_sums[pidx] = L;
+      if (p.counters != nullptr) {  // in-kernel reduce: write-through (agent-scope) stores, see v2_last_arriver_reduce
+        __hip_atomic_store(p.max_logits + pidx, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.exp_sums + pidx, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        p.max_logits[pidx] = M;
+        p.exp_sums[pidx] = L;
+      }
     }
   } else {
     outp = reinterpret_cast<scalar_t*>(p.out) + ((int64_t)seq * p.num_heads + chead) * D;
@@ -441,7 +556,10 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
         r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
         amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(r.h[j])));  // of the ROUNDED output: what a later absmax pass would see
       }
-      *reinterpret_cast<u32x2*>(outp + d0) = r.u;
+      if (p.partitioned && p.counters != nullptr)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(outp + d0), __builtin_bit_cast(uint64_t, r.u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        *reinterpret_cast<u32x2*>(outp + d0) = r.u;
     }
   }
   if (p.absmax != nullptr && !p.partitioned) {  // (uniform) one maximum per workgroup
@@ -456,6 +574,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128) ? 2 : 1) void paged_attention_k
       p.absmax[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
     }
   }
+  if (p.partitioned && p.counters != nullptr) v2_last_arriver_reduce<scalar_t, NW>(p, seq, kvh, qt, seq_len, D, reinterpret_cast<float*>(smem));
 }
 
 // ---- fp8 KV cache, block_size >= 16: 64-token tiles with 16-byte loads ---------------------------------------------
@@ -723,8 +842,13 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
     const int64_t pidx = ((int64_t)seq * p.num_heads + chead) * p.max_num_partitions + part;
     outp = reinterpret_cast<scalar_t*>(p.out) + pidx * D;
     if ((t >> 4) == 0 && active) {
-      p.max_logits[pidx] = M;
-      p.exp_sums[pidx] = L;
+      if (p.counters != nullptr) {  // in-kernel reduce: write-through (agent-scope) stores, see v2_last_arriver_reduce
+        __hip_atomic_store(p.max_logits + pidx, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.exp_sums + pidx, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        p.max_logits[pidx] = M;
+        p.exp_sums[pidx] = L;
+      }
     }
   } else {
     outp = reinterpret_cast<scalar_t*>(p.out) + ((int64_t)seq * p.num_heads + chead) * D;
@@ -746,7 +870,10 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
         r.h[j] = Scalar<scalar_t>::from_f32(acc[j]);
         amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(r.h[j])));  // of the ROUNDED output: what a later absmax pass would see
       }
-      *reinterpret_cast<u32x2*>(outp + d0) = r.u;
+      if (p.partitioned && p.counters != nullptr)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(outp + d0), __builtin_bit_cast(uint64_t, r.u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        *reinterpret_cast<u32x2*>(outp + d0) = r.u;
     }
   }
   if (p.absmax != nullptr && !p.partitioned) {  // (uniform) one maximum per workgroup
@@ -761,6 +888,7 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_attention_fp8w_kernel(const 
       p.absmax[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
     }
   }
+  if (p.partitioned && p.counters != nullptr) v2_last_arriver_reduce<scalar_t, NW>(p, seq, kvh, qt, seq_len, D, reinterpret_cast<float*>(smem));
 }
 
 
@@ -775,45 +903,10 @@ __global__ void paged_attention_v2_reduce_kernel(scalar_t* __restrict__ out, con
   const int seq_len = seq_lens[seq];
   const int np = (seq_len + part_size - 1) / part_size;
   const int64_t pb = ((int64_t)seq * num_heads + head) * max_num_partitions;
-  scalar_t* o = out + ((int64_t)seq * num_heads + head) * head_size;
-  const scalar_t* tp = tmp_out + pb * head_size;
-  float amax = 0.f;
-  if (np <= 1) {
-    for (int i = threadIdx.x; i < head_size; i += blockDim.x) {
-      o[i] = tp[i];
-      amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(tp[i])));
-    }
-    if (absmax != nullptr) {
-      amax = wave_reduce_max(amax);
-      if (threadIdx.x == 0) absmax[(int64_t)seq * num_heads + head] = amax;
-    }
-    return;
-  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* resc = reinterpret_cast<float*>(smem);  // [np]
-  float m = -FLT_MAX;
-  for (int i = threadIdx.x; i < np; i += 64) m = fmaxf(m, max_logits[pb + i]);
-  m = wave_reduce_max(m);
-  float gsum = 0.f;
-  for (int i = threadIdx.x; i < np; i += 64) {
-    const float r = exp_sums[pb + i] * __expf(max_logits[pb + i] - m);
-    resc[i] = r;
-    gsum += r;
-  }
-  gsum = wave_reduce_sum(gsum);
-  __syncthreads();
-  const float inv = __fdividef(1.f, gsum + 1e-6f);
-  for (int d = threadIdx.x; d < head_size; d += 64) {
-    float acc = 0.f;
-    for (int j = 0; j < np; ++j) acc += Scalar<scalar_t>::to_f32(tp[(int64_t)j * head_size + d]) * resc[j] * inv;
-    const scalar_t ov = Scalar<scalar_t>::from_f32(acc);
-    o[d] = ov;
-    amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(ov)));
-  }
-  if (absmax != nullptr) {
-    amax = wave_reduce_max(amax);
-    if (threadIdx.x == 0) absmax[(int64_t)seq * num_heads + head] = amax;
-  }
+  v2_reduce_head<scalar_t>(out + ((int64_t)seq * num_heads + head) * head_size, exp_sums + pb, max_logits + pb, tmp_out + pb * head_size,
+                           np, head_size, absmax != nullptr ? absmax + (int64_t)seq * num_heads + head : nullptr,
+                           reinterpret_cast<float*>(smem), (int)threadIdx.x);
 }
 
 // ---- float32 queries / float32 or fp8 cache (attention_kernels.cu:742-803 instantiates `float` too) -------------
@@ -1043,7 +1136,7 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
                   float scale, const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
                   int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
                   int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
-                  hipStream_t stream, int part_size = kPartitionSize) {
+                  hipStream_t stream, int part_size = kPartitionSize, int* counters = nullptr) {
   NMX_CHECK(part_size >= 64 && part_size <= kPartitionSize && part_size % 64 == 0, NMX_ERR_INVALID_ARG,
             "paged_attention: partition size %d (64 .. 512, a multiple of 64)", part_size);
   NMX_CHECK(block_size == 8 || block_size == 16 || block_size == 32, NMX_ERR_UNSUPPORTED,
@@ -1087,6 +1180,9 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
   const int num_partitions = partitioned ? (max_seq_len + part_size - 1) / part_size : 1;
   p.max_num_partitions = num_partitions;
   p.part_size = part_size;
+  // in-kernel reduce by the last-arriving partition: the MFMA kernels only (fp16 / bf16 queries), a sane partition count
+  p.counters = (partitioned && dtype != NMX_F32 && num_partitions <= 512) ? counters : nullptr;
+  p.final_out = out;
   p.sparse = bs_vert_stride > 1 ? 1 : 0;  // attention_kernels.cu:822
   p.tp_rank = tp_rank;
   p.bs_local_blocks = bs_local_blocks;
@@ -1100,7 +1196,7 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
   if (dtype == NMX_F32) rc = launch_attn_f32(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
   else if (dtype == NMX_F16) rc = dispatch_kv<f16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
   else rc = dispatch_kv<bf16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
-  if (rc != NMX_OK || !partitioned) return rc;
+  if (rc != NMX_OK || !partitioned || p.counters != nullptr) return rc;
 
   dim3 rgrid(num_heads, num_seqs);
   const size_t rsmem = (size_t)num_partitions * sizeof(float);
@@ -1199,7 +1295,11 @@ extern "C" int nmx_paged_attention_v2_absmax(void* out, float* absmax, float* ex
 // 256 KiB of K / V at ONE CU's rate): the decode mirror of PagedAttention.forward_decode asks
 // nmx_paged_attention_partition_size() and, when it answers less than 512, allocates its own exp_sums / max_logits / tmp_out
 // for ceil(max_seq_len / partition_size) partitions and calls this entry. Same arithmetic per partition and the same reduce
-// kernel; only the split of the softmax sum differs (as between v1 and v2). absmax may be null.
+// arithmetic; only the split of the softmax sum differs (as between v1 and v2). absmax may be null.
+// counters (may be null): int32 [nmx_paged_attention_counters_numel(...)], ALL ZERO before the call and all zero again after
+// it, used by no other launch in flight - with it the last-arriving partition workgroup of every (sequence, kv head) reduces
+// the partitions itself (v2_last_arriver_reduce) and no reduce kernel is launched: one dependent launch less (fp16 / bf16
+// queries; float32 queries ignore it). The output bits are those of the reduce kernel.
 extern "C" int nmx_paged_attention_partition_size(int num_seqs, int num_heads, int num_kv_heads, int max_seq_len) {
   if (num_seqs <= 0 || num_heads <= 0 || num_kv_heads <= 0) return kPartitionSize;
   const int q_tiles = (num_heads / num_kv_heads + 15) / 16;
@@ -1220,10 +1320,16 @@ extern "C" int nmx_paged_attention_v2_ps(void* out, float* absmax, float* exp_su
                                          const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
                                          int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale,
                                          int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
-                                         int bs_head_sliding_step, int partition_size, nmx_stream_t stream) {
+                                         int bs_head_sliding_step, int partition_size, int* counters, nmx_stream_t stream) {
+  NMX_CHECK(counters == nullptr || (uintptr_t)counters % 4 == 0, NMX_ERR_INVALID_ARG, "paged_attention_v2_ps: counters misaligned");
   return run_attention(true, out, absmax, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
                        num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale,
                        block_tables, max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype,
                        kv_scale, tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step,
-                       (hipStream_t)stream, partition_size);
+                       (hipStream_t)stream, partition_size, counters);
+}
+
+extern "C" int64_t nmx_paged_attention_counters_numel(int num_seqs, int num_heads, int num_kv_heads) {
+  if (num_seqs <= 0 || num_heads <= 0 || num_kv_heads <= 0) return 0;
+  return (int64_t)num_seqs * num_kv_heads * ((num_heads / num_kv_heads + 15) / 16);
 }

@@ -340,3 +340,78 @@ def test_paged_attention_v2_fine_partitions(ops, tune, part, kv_dtype, dtype, nu
     if part == "64":
         tune(NMX_ATTN_PART="96")  # not a multiple of 64: the library answers the contract's 512
         assert _lib.lib().nmx_paged_attention_partition_size(num_seqs, nq, nkv, max_len) == 512
+
+
+@pytest.mark.parametrize("kv_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("num_seqs,nq,nkv,head_size,part", [(1, 32, 8, 128, None), (4, 32, 8, 128, "128"), (3, 40, 2, 128, "64"),
+                                                             (2, 12, 12, 64, "256")])
+def test_paged_attention_v2_inkernel_reduce(ops, tune, monkeypatch, kv_dtype, dtype, num_seqs, nq, nkv, head_size, part):
+    """Round 3 (late): with fine partitions the reduce runs inside the attention kernel - the last partition workgroup to
+    arrive at a (sequence, kv head, q tile) reduces its heads (v2_last_arriver_reduce), no reduce launch. Same bits as the
+    two-launch form (NMX_ATTN_INKERNEL_REDUCE=0: the reduce kernel, the same device function), counters back at zero, and the
+    result does not change over 200 back-to-back launches with ragged sequence lengths (a stale read of another workgroup's
+    partial would show as a flicker)."""
+    from neuralmagic_vllm_amd import _custom_ops
+    seed_all(nq + head_size + num_seqs)
+    block_size = 16
+    scale = float(head_size**-0.5)
+    q = torch.empty(num_seqs, nq, head_size, dtype=dtype).uniform_(-scale, scale)
+    seq_lens = [1024, 129, 577, 1000][:num_seqs]
+    max_len = max(seq_lens)
+    mb = (max_len + block_size - 1) // block_size
+    bt = torch.tensor([[random.randint(0, 255) for _ in range(mb)] for _ in range(num_seqs)], dtype=torch.int32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    kcs, vcs = create_kv_caches_with_random(256, block_size, 1, nkv, head_size, kv_dtype, dtype)
+    kv_scale = 0.75 if kv_dtype != "auto" else 1.0
+    tune(NMX_ATTN_PART=part)
+    qg, kc, vc, btg, slg = q.to(DEV), kcs[0].to(DEV), vcs[0].to(DEV), bt.to(DEV), sl.to(DEV)
+    P = (max_len + PARTITION - 1) // PARTITION
+    tmp = torch.empty(num_seqs, nq, P, head_size, dtype=dtype, device=DEV)
+    es = torch.empty(num_seqs, nq, P, dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+
+    def run(absmax=False):  # (qg: the binding at call time)
+        out = torch.full_like(qg, float("nan"))
+        if absmax:
+            am = ops.paged_attention_v2_absmax(out, es, ml, tmp, qg, kc, vc, nkv, scale, btg, slg, block_size, max_len, None, kv_dtype, kv_scale)
+            return out, am
+        ops.paged_attention_v2(out, es, ml, tmp, qg, kc, vc, nkv, scale, btg, slg, block_size, max_len, None, kv_dtype, kv_scale)
+        return out, None
+
+    monkeypatch.setenv("NMX_ATTN_INKERNEL_REDUCE", "0")
+    two, two_am = run(absmax=True)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("NMX_ATTN_INKERNEL_REDUCE", "1")
+    one, one_am = run(absmax=True)
+    torch.cuda.synchronize()
+    assert not torch.isnan(one.float()).any()
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16)) and torch.equal(one_am, two_am)
+    # back-to-back launches on ALTERNATING inputs (the temporaries come back at the same addresses: a stale read of another
+    # workgroup's partial would return the other input's values), under load from a second stream that keeps the CUs' caches busy
+    qg2 = torch.empty_like(qg).uniform_(-scale, scale)
+    q_first = qg
+    monkeypatch.setenv("NMX_ATTN_INKERNEL_REDUCE", "0")
+    qg = qg2
+    two_b = run()[0]
+    torch.cuda.synchronize()
+    monkeypatch.setenv("NMX_ATTN_INKERNEL_REDUCE", "1")
+    assert not torch.equal(two_b.view(torch.int16), two.view(torch.int16))
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    outs = []
+    for i in range(200):
+        if i % 8 == 0:
+            with torch.cuda.stream(side):
+                junk.add_(1)
+        qg = q_first if i % 2 == 0 else qg2
+        outs.append(run()[0])
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        want = two if i % 2 == 0 else two_b
+        assert torch.equal(o.view(torch.int16), want.view(torch.int16)), f"launch {i}"
+    qg = q_first
+    for buf in _custom_ops._V2_COUNTERS.values():
+        assert int(buf.abs().max()) == 0
+    orc = run_oracle("v2", q, kcs[0], vcs[0], nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
+    torch.testing.assert_close(one.cpu().float(), orc.float(), atol=1e-3 if kv_dtype == "auto" else 1e-2, rtol=1e-5)
