@@ -1308,8 +1308,14 @@ extern "C" int nmx_paged_attention_partition_size(int num_seqs, int num_heads, i
     const int v = atoi(e);
     return (v >= 64 && v <= kPartitionSize && v % 64 == 0) ? v : kPartitionSize;
   }
-  // halve while the finer split still fits one round of the 256 CUs and a partition keeps >= 128 tokens
-  while (ps > 128 && (long)num_seqs * num_kv_heads * q_tiles * ((max_seq_len + ps / 2 - 1) / (ps / 2)) <= 256) ps /= 2;
+  // halve while the finer split still fits one round of the 256 CUs, a partition keeps >= 128 tokens and a sequence has at most
+  // 8 partitions (the reduce walks them one by one: at 4,096 / 8,192 tokens of context the contract's 512 is already the
+  // best or within 4 % of it - tools/attn_part_sweep.py, profiles/r03_attn_part_sweep.txt)
+  while (ps > 128) {
+    const int np = (max_seq_len + ps / 2 - 1) / (ps / 2);
+    if (np > 8 || (long)num_seqs * num_kv_heads * q_tiles * np > 256) break;
+    ps /= 2;
+  }
   return ps;
 }
 
