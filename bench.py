@@ -101,6 +101,8 @@ def parse():
     ap.add_argument("--attn", choices=["auto", "v1", "v2"], default="auto", help="decode attention op: auto = the reference's rule "
                     "(paged_attn.py:120-121)")
     ap.add_argument("--no-act-fuse", action="store_true", help="int4: gate_up GEMM and silu_and_mul as two ops (A/B of the fused epilogue)")
+    ap.add_argument("--attn-fuse", action="store_true", help="int4: paged_attention_v2's partition launch, then o_proj with the reduce in "
+                    "its prologue (needs NMX_GEMM_ATTN=rows in the environment; measured level with the reduce launch, off by default)")
     ap.add_argument("--no-norm-fuse", action="store_true", help="int4: fused_add_rms_norm and the GEMM behind it as two ops (A/B of the "
                     "norm-fused GEMM prologue at batch <= 4)")
     ap.add_argument("--no-attn-absmax", action="store_true", help="fp8: separate absmax pass over the attention output (A/B of paged_attention_v1/v2_absmax)")
@@ -155,6 +157,7 @@ class Llama3Decode:
         self.fuse = False  # int4 only: deferred split-K reduction + rotary / cache fusion (set by main)
         self.act_fuse = True  # int4: gate_up + silu_and_mul as one op (set by main)
         self.attn_absmax = True  # fp8: paged attention leaves the maxima of its output (set by main)
+        self.attn_fuse = False  # int4: paged_attention_v2's reduce inside o_proj's prologue (off: level with the reduce launch; set by main)
         self.norm_fuse = True  # int4: fused_add_rms_norm + the GEMM behind it as one op (one launch at batch <= 4; set by main)
         self.n_layers = n_layers
         self.variant = variant
@@ -302,8 +305,16 @@ class Llama3Decode:
             qkv_next = None
             qkv = ops.rope_reshape_and_cache(self.positions, qkv_g, nh, nkv, D, self.cos_sin_cache, kc, vc,
                                              self.slot_mapping, self.kv_dtype, self.kv_scale)
-            a = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li)
-            o = gemm(a.view(-1, nh * D), lw["o"], "o")
+            if self.variant == "int4" and self.attn_fuse and not self.use_v1:
+                # v2's partition launch, then o_proj with the reduce in its prologue (one launch at batch <= 16, else reduce + GEMM)
+                parts = ops.paged_attention_v2_partials(qkv[:, :self.q_size].view(-1, nh, D), kc, vc, nkv, self.scale, self.block_tables,
+                                                        self.seq_lens, self.BS, self.L, None, self.kv_dtype, self.kv_scale)
+                K, N = self.shapes["o"]
+                w = lw["o"]
+                o = ops.paged_attention_gptq_marlin_gemm(parts, w[0], w[1], e, e, ws, 4, self.B, N, K, True)
+            else:
+                a = self.attention(qkv[:, :self.q_size].view(-1, nh, D), li)
+                o = gemm(a.view(-1, nh * D), lw["o"], "o")
             if self.all_reduce is not None:
                 self.all_reduce(o.materialize())
             if self.variant == "int4" and self.act_fuse and self.norm_fuse:
@@ -647,6 +658,7 @@ def main():
     model.act_fuse = not args.no_act_fuse
     model.attn_absmax = not args.no_attn_absmax
     model.norm_fuse = not args.no_norm_fuse
+    model.attn_fuse = args.attn_fuse
     model.fuse = (args.config in ("int4", "fp8", "sparse24") or awq_fusable) and not args.no_fuse and (args.config != "fp8" or tp == 0)
     model.step()  # eager once: allocates GEMM scratch outside capture
     torch.cuda.synchronize()

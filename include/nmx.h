@@ -119,6 +119,20 @@ int nmx_paged_attention_v2_ps(void* out, float* absmax, float* exp_sums, float* 
  * partitions itself and no reduce kernel is launched (fp16 / bf16 queries; same output bits). */
 int64_t nmx_paged_attention_counters_numel(int num_seqs, int num_heads, int num_kv_heads);
 
+/* paged_attention_v2 in two halves (no reference counterpart): the partition launch alone - exp_sums / max_logits / tmp_out as
+ * for nmx_paged_attention_v2_ps, nothing reduced - and the reduce (csrc/attention/attention_kernels.cu:567-669) as an op of its own.
+ * nmx_gptq_marlin_gemm_attn (below) takes the partition results directly. */
+int nmx_paged_attention_v2_partials(float* exp_sums, float* max_logits, void* tmp_out, const void* query, const void* key_cache,
+                                    const void* value_cache, int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                    int block_size, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                                    const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens, int max_seq_len,
+                                    const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
+                                    int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
+                                    int partition_size, nmx_stream_t stream);
+int nmx_paged_attention_v2_reduce(void* out, const float* exp_sums, const float* max_logits, const void* tmp_out,
+                                  const int32_t* seq_lens, int num_seqs, int num_heads, int head_size, int max_num_partitions,
+                                  int partition_size, int dtype, nmx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * KV-cache ops. Replace csrc/cache_kernels.cu (schema csrc/torch_bindings.cpp:207-244, csrc/cache.h:8-32).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -231,6 +245,18 @@ int nmx_gptq_marlin_gemm_norm(const float* norm_partial, int norm_splits, const 
                               void* act_out, int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int size_m,
                               int size_n, int size_k, int num_bits, int num_groups, int dtype, int* splits_out,
                               nmx_stream_t stream);
+/* paged_attention_v2's reduce + o_proj as ONE launch at batch <= 16 (no reference counterpart: attention_kernels.cu:567-669 runs
+ * inside the attention op, o_proj afterwards - vllm/model_executor/models/llama.py:171-172). The GEMM's A operand
+ * [size_m = sequences, size_k = num_heads x 128] is the v2 reduce of what nmx_paged_attention_v2_partials left; every wave reduces
+ * the heads of its own K slice in its prologue (the reduce kernel's arithmetic: same bits). c / scratch / *splits_out as
+ * nmx_gptq_marlin_gemm_deferred. nmx_gptq_marlin_gemm_attn_supported() says which shapes are served (4 bits, no act-order, head size
+ * 128, size_m <= 16, the decode kernel's shapes); others return NMX_ERR_UNSUPPORTED - run nmx_paged_attention_v2_reduce + the GEMM. */
+int nmx_gptq_marlin_gemm_attn_supported(int size_m, int size_n, int size_k, int num_groups, int num_bits, int dtype, int num_heads,
+                                        int head_size, int max_num_partitions);
+int nmx_gptq_marlin_gemm_attn(const float* exp_sums, const float* max_logits, const void* tmp_out, const int32_t* seq_lens,
+                              int partition_size, int max_num_partitions, int num_heads, int head_size, const int32_t* b_q_weight,
+                              const void* b_scales, void* c, int64_t workspace_numel, void* scratch, int64_t scratch_bytes, int size_m,
+                              int size_n, int size_k, int num_bits, int num_groups, int dtype, int* splits_out, nmx_stream_t stream);
 /* fused_add_rms_norm (csrc/layernorm_kernels.cu:258-291) on x = round(sum_s partial[s]): residual += x,
  * input_out = rms_norm(residual) * weight. partial [splits, num_tokens, hidden] fp32, splits >= 2. */
 int nmx_fused_add_rms_norm_splitk(void* input_out, const float* partial, int splits, void* residual, const void* weight,

@@ -337,6 +337,72 @@ def paged_attention_v2_absmax(out, exp_sum, max_logits, tmp_out, query, key_cach
     return amax
 
 
+class AttnPartials:
+    """Partition results of paged_attention_v2_partials: exp_sums / max_logits [S, H, P], tmp [S, H, P, D]; the reduce has not
+    run. Hand it to paged_attention_gptq_marlin_gemm (o_proj reduces in its prologue) or call materialize()."""
+    __slots__ = ("exp_sums", "max_logits", "tmp", "seq_lens", "part", "out")
+
+    def __init__(self, exp_sums, max_logits, tmp, seq_lens, part):
+        self.exp_sums, self.max_logits, self.tmp, self.seq_lens, self.part, self.out = exp_sums, max_logits, tmp, seq_lens, part, None
+
+    def materialize(self) -> torch.Tensor:
+        """The attention output [S, H, D] (the reduce kernel as a launch of its own)."""
+        if self.out is None:
+            S, H, P, D = self.tmp.shape
+            self.out = torch.empty(S, H, D, dtype=self.tmp.dtype, device=self.tmp.device)
+            _lib.check(_lib.lib().nmx_paged_attention_v2_reduce(_p(self.out), _p(self.exp_sums), _p(self.max_logits), _p(self.tmp),
+                                                                _p(self.seq_lens), c_int(S), c_int(H), c_int(D), c_int(P),
+                                                                c_int(self.part), c_int(_dt(self.tmp)), _stream(self.tmp)))
+        return self.out
+
+
+def paged_attention_v2_partials(query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                                alibi_slopes, kv_cache_dtype, kv_scale, tp_rank=0, blocksparse_local_blocks=0,
+                                blocksparse_vert_stride=0, blocksparse_block_size=64, blocksparse_head_sliding_step=0) -> AttnPartials:
+    """paged_attention_v2's partition launch alone (partition size: the library's choice, see _v2_fine_partition)."""
+    ps = _lib.lib().nmx_paged_attention_partition_size(c_int(query.shape[0]), c_int(query.shape[1]), c_int(num_kv_heads),
+                                                       c_int(max_seq_len))
+    num_seqs, num_heads, head_size = query.shape
+    parts = (max_seq_len + ps - 1) // ps
+    tmp = torch.empty(num_seqs, num_heads, parts, head_size, dtype=query.dtype, device=query.device)
+    sums = torch.empty(2, num_seqs, num_heads, parts, dtype=torch.float32, device=query.device)
+    _attn_common(_lib.lib().nmx_paged_attention_v2_partials, (_p(sums[0]), _p(sums[1]), _p(tmp)), query, key_cache, value_cache,
+                 num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
+                 blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step,
+                 tail_args=(c_int(ps), ))
+    return AttnPartials(sums[0], sums[1], tmp, seq_lens, ps)
+
+
+def paged_attention_gptq_marlin_gemm(partials: AttnPartials, b_q_weight: torch.Tensor, b_scales: torch.Tensor, g_idx: torch.Tensor,
+                                     perm: torch.Tensor, workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int, size_k: int,
+                                     is_k_full: bool) -> "DeferredGemm":
+    """o_proj on the attention output of paged_attention_v2_partials (LlamaAttention.forward, models/llama.py:171-172), as
+    gptq_marlin_gemm_deferred returns it. At batch <= 16 (head size 128, int4 without act-order, the decode kernel's 4-wave
+    shape: nmx_gptq_marlin_gemm_attn_supported) the GEMM reduces the partitions in its prologue - every wave the heads of its
+    own K slice, with the reduce kernel's device function - and no reduce kernel is launched; otherwise reduce launch + GEMM.
+    Same bits either way (tests/test_fused_gpu.py::test_attn_reduce_gemm)."""
+    S, H, P, D = partials.tmp.shape
+    has_idx = g_idx is not None and g_idx.numel() > 0
+    fused = (partials.out is None and not has_idx and size_m == S and size_k == H * D and
+             _lib.lib().nmx_gptq_marlin_gemm_attn_supported(c_int(size_m), c_int(size_n), c_int(size_k), c_int(b_scales.shape[0]),
+                                                            c_int(num_bits), c_int(_dt(partials.tmp)), c_int(H), c_int(D), c_int(P)))
+    if not fused:
+        a = partials.materialize().view(S, H * D)
+        return gptq_marlin_gemm_deferred(a, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, size_m, size_n, size_k, is_k_full)
+    t = partials.tmp
+    c = torch.empty((size_m, size_n), dtype=t.dtype, device=t.device)
+    scratch = _marlin_scratch(t, size_m, size_n, size_k)
+    splits = c_int(1)
+    _lib.check(_lib.lib().nmx_gptq_marlin_gemm_attn(
+        _p(partials.exp_sums), _p(partials.max_logits), _p(t), _p(partials.seq_lens), c_int(partials.part), c_int(P), c_int(H), c_int(D),
+        _p(b_q_weight), _p(b_scales), _p(c), c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n),
+        c_int(size_k), c_int(num_bits), c_int(b_scales.shape[0]), c_int(_dt(t)), ctypes.byref(splits), _stream(t)))
+    if (splits.value & 0xff) > 1:
+        partial, n = _slabs(scratch, splits.value, size_m, size_n)
+        return DeferredGemm(c, partial, n)
+    return DeferredGemm(c, None, 1)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # KV-cache ops (vllm/_custom_ops.py:370-412)
 # ---------------------------------------------------------------------------------------------------------

@@ -23,7 +23,11 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   p.M = size_m; p.N = size_n; p.K = size_k; p.num_groups = num_groups; p.k_splits = 1; p.slow_act_order = 0;
   p.defer_reduce = defer_reduce;
   p.act_out = act_out;
-  if (norm != nullptr) {
+  if (norm != nullptr && norm->attn_tmp != nullptr) {
+    p.attn_exp_sums = norm->attn_exp_sums; p.attn_max_logits = norm->attn_max_logits; p.attn_tmp = norm->attn_tmp;
+    p.attn_seq_lens = norm->attn_seq_lens; p.attn_part_size = norm->attn_part_size; p.attn_max_parts = norm->attn_max_parts;
+    p.attn_heads = norm->attn_heads;
+  } else if (norm != nullptr) {
     p.norm_partial = norm->norm_partial; p.norm_splits = norm->norm_splits; p.norm_res_in = norm->norm_res_in;
     p.norm_res_out = norm->norm_res_out; p.norm_weight = norm->norm_weight; p.norm_eps = norm->norm_eps;
   }
@@ -46,9 +50,14 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   }
   if (num_groups > 1 && !p.slow_act_order)
     NMX_CHECK(p.group_size % 32 == 0, NMX_ERR_UNSUPPORTED, "group_size = %d must be a multiple of 32", p.group_size);
-  NMX_CHECK(norm == nullptr || (kind == W_INT4 && !has_act_order && dtype == NMX_F16 &&
-                                decode_norm_supported(size_m, size_n, size_k, num_groups, act_out != nullptr)),
+  NMX_CHECK(norm == nullptr || norm->attn_tmp != nullptr ||
+                (kind == W_INT4 && !has_act_order && dtype == NMX_F16 &&
+                 decode_norm_supported(size_m, size_n, size_k, num_groups, act_out != nullptr)),
             NMX_ERR_UNSUPPORTED, "norm-fused gptq_marlin_gemm: fp16, int4 without act-order, shapes of nmx_gptq_marlin_gemm_norm_supported");
+  NMX_CHECK(norm == nullptr || norm->attn_tmp == nullptr ||
+                (kind == W_INT4 && !has_act_order && act_out == nullptr &&
+                 decode_attn_supported(size_m, size_n, size_k, num_groups, norm->attn_heads, 128, norm->attn_max_parts)),
+            NMX_ERR_UNSUPPORTED, "attention-reduce gptq_marlin_gemm: int4 without act-order, shapes of nmx_gptq_marlin_gemm_attn_supported");
   NMX_CHECK(((uintptr_t)a % 16 == 0) && ((uintptr_t)b_q_weight % 16 == 0) && ((uintptr_t)b_scales % 16 == 0) &&
                 ((uintptr_t)c % 8 == 0) && size_k % 8 == 0,
             NMX_ERR_INVALID_ARG, "marlin gemm: operands must be 16-byte aligned");
@@ -224,4 +233,34 @@ extern "C" int nmx_gptq_marlin_gemm_norm(const float* norm_partial, int norm_spl
   if (rc == NMX_OK && act_out != nullptr && !done && size_m > 0 && size_n > 0)
     NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "norm-fused gate_up: the dispatch did not take the fused-activation shape");
   return rc;
+}
+
+// ---- paged_attention_v2's reduce + o_proj as ONE launch at batch <= 16 (round 3, late; no reference counterpart: the reference
+// runs paged_attention_v2_reduce_kernel inside the attention op and o_proj afterwards, csrc/attention/attention_kernels.cu:567-669,
+// vllm/model_executor/models/llama.py:171-172). The GEMM's A operand [size_m = sequences, size_k = heads x 128] is the v2 reduce of
+// the partition results nmx_paged_attention_v2_partials left (exp_sums / max_logits [seqs, heads, max_parts], tmp_out [seqs, heads,
+// max_parts, 128]); every wave of marlin_decode_kernel reduces the heads of its own K slice in its prologue with the reduce
+// kernel's device function (same bits as the two ops), no reduce launch. c / scratch / *splits_out as nmx_gptq_marlin_gemm_deferred.
+extern "C" int nmx_gptq_marlin_gemm_attn_supported(int size_m, int size_n, int size_k, int num_groups, int num_bits, int dtype,
+                                                   int num_heads, int head_size, int max_num_partitions) {
+  return num_bits == 4 && (dtype == NMX_F16 || dtype == NMX_BF16) &&
+                 decode_attn_supported(size_m, size_n, size_k, num_groups, num_heads, head_size, max_num_partitions)
+             ? 1 : 0;
+}
+
+extern "C" int nmx_gptq_marlin_gemm_attn(const float* exp_sums, const float* max_logits, const void* tmp_out, const int32_t* seq_lens,
+                                         int partition_size, int max_num_partitions, int num_heads, int head_size,
+                                         const int32_t* b_q_weight, const void* b_scales, void* c, int64_t workspace_numel,
+                                         void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_bits,
+                                         int num_groups, int dtype, int* splits_out, nmx_stream_t stream) {
+  NMX_CHECK(num_bits == 4 && head_size == 128, NMX_ERR_UNSUPPORTED, "attention-reduce gptq_marlin_gemm: 4 bits, head size 128");
+  NMX_CHECK(exp_sums != nullptr && max_logits != nullptr && tmp_out != nullptr && seq_lens != nullptr && splits_out != nullptr &&
+                partition_size >= 64 && partition_size % 64 == 0 && max_num_partitions >= 1,
+            NMX_ERR_INVALID_ARG, "attention-reduce gptq_marlin_gemm: partition results, seq_lens, splits_out; partition size a multiple of 64");
+  NMX_CHECK(((uintptr_t)tmp_out % 16) == 0, NMX_ERR_INVALID_ARG, "attention-reduce gptq_marlin_gemm: tmp_out must be 16-byte aligned");
+  GemmParams n;
+  n.attn_exp_sums = exp_sums; n.attn_max_logits = max_logits; n.attn_tmp = tmp_out; n.attn_seq_lens = seq_lens;
+  n.attn_part_size = partition_size; n.attn_max_parts = max_num_partitions; n.attn_heads = num_heads;
+  return marlin_common(tmp_out, b_q_weight, b_scales, nullptr, nullptr, c, workspace_numel, scratch, scratch_bytes, size_m, size_n,
+                       size_k, W_INT4, num_groups, 1, dtype, (hipStream_t)stream, 1, splits_out, nullptr, nullptr, &n);
 }

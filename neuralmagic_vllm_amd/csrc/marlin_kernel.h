@@ -232,6 +232,13 @@ struct GemmParams {
   void* norm_res_out = nullptr;         // [M, K] scalar_t
   const void* norm_weight = nullptr;    // [K] scalar_t
   float norm_eps = 0.f;
+  // marlin_decode_kernel<ATTN> (round 3, late): the A operand is the v2 reduce of paged attention's partition results - row m =
+  // sequence m, k = head * 128 + d - computed by every wave for the heads of its own K slice (a is unused)
+  const float* attn_exp_sums = nullptr;   // [M, heads, max_parts]
+  const float* attn_max_logits = nullptr; // [M, heads, max_parts]
+  const void* attn_tmp = nullptr;         // [M, heads, max_parts, 128] scalar_t
+  const int32_t* attn_seq_lens = nullptr; // [M]
+  int attn_part_size = 0, attn_max_parts = 0, attn_heads = 0;
 };
 constexpr int kNormMaxRows = 4;         // rows the norm-fused kernel can take (every workgroup recomputes the norm of all rows)
 // threads / vectors per thread of rms_norm_splitk_kernel for a hidden size (elementwise.hip add_rms_norm_splitk_common): the
@@ -1204,9 +1211,11 @@ __device__ __forceinline__ u32x4 frag_transpose(u32x4 v) {
   return u32x4{p01[0], p01[1], p23[0], p23[1]};
 }
 
-template <typename scalar_t, int MT, int NW, bool GROUPED, bool WS, bool NORM = false>
+template <typename scalar_t, int MT, int NW, bool GROUPED, bool WS, bool NORM = false, bool ATTN = false>
 __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_kernel(const GemmParams p) {
-  static_assert(!NORM || MT == 1, "the norm-fused form takes one 16-row tile");
+  static_assert(!(NORM || ATTN) || MT == 1, "the forms with a computed A operand take one 16-row tile");
+  static_assert(!(NORM && ATTN), "one computed A operand at a time");
+  constexpr bool LDSA = NORM || ATTN;  // the A operand is computed in the prologue and read from LDS
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15, c8 = li & 7, hi = li >> 3;
@@ -1263,8 +1272,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
   // loads of one 32-k step / of the scale rows of unit u (past the slice: the last unit again, never consumed)
   // NORM: the normalised rows live in LDS behind the reduction image - row r at r * XS (XS = 2 K + 64: four rows land in
   // different 64-byte bank quarters), row M is all zeros and serves the tile's unused rows
+  // ATTN: a row holds only the workgroup's K slice (units abase .. abase + nslice * per), every wave fills and reads its own part
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int XS = 2 * K + 64;
+  const int abase = ATTN ? (int)blockIdx.y * nslice * per : 0;  // first unit of the LDS rows
+  const int XS = ATTN ? nslice * per * 256 + 64 : 2 * K + 64;
   char* const xl = smem + NW * MT * 4096;
   const char* const xl_lane = xl + min(li, M) * XS + 16 * g;
   // WQ / WA: the weight-side (vector-memory) and the activation-side half of a step; the NORM prologue issues them apart
@@ -1273,8 +1284,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
     // aux 2 = non-temporal: the weights are read once (this kernel is used with one row block; a constant, because a
     // branch around the load halves the wait counts hipcc can prove)
     if (WQ) U.q[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff, (u * 8 + 2 * ks) * row_bytes, NMX_W_NT ? 2 : 0);
-    if constexpr (NORM) {
-      if (WA) U.a[ks][0] = *reinterpret_cast<const u32x4*>(xl_lane + (u * 128 + ks * 32) * 2);
+    if constexpr (LDSA) {
+      // (ATTN: past the wave's slice the last own unit again - the row holds nothing beyond the workgroup's slice)
+      const int ua_ = ATTN ? min(u, max(u1 - 1, u0)) - abase : u;
+      if (WA) U.a[ks][0] = *reinterpret_cast<const u32x4*>(xl_lane + (ua_ * 128 + ks * 32) * 2);
     } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -1450,8 +1463,44 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
       load_unit(u0 + 1, ub, false, true);
     }
   }
+  if constexpr (ATTN) {
+    // ---- the A operand: paged attention's v2 reduce (v2_reduce_head, the device function of the reduce kernel: same bits) of
+    //      the heads this wave's K slice covers - unit u = head u (head size 128), row m = sequence m. Wave-private: a wave
+    //      reads back only what it wrote; the one barrier publishes the zero row. ----
+    if (u0 < u1) {
+      load_unit(u0, ua, true, false);
+      load_unit(u0 + 1, ub, true, false);
+    }
+    for (int e = threadIdx.x; e < XS / 16; e += 64 * NW) *reinterpret_cast<u32x4*>(xl + M * XS + e * 16) = u32x4{0, 0, 0, 0};
+    // lane c of the wave's (u1 - u0) x 32 chunks: head u0 + c / 32, dimensions 4 (c % 32) .. + 3; rows four at a time, every load
+    // of the four rows in flight before the first is consumed (v2_vec4_*: at most 8 partitions, the host checks)
+    const int nchunks = max(u1 - u0, 0) * 32;
+    for (int c = lane; c < nchunks; c += 64) {
+      const int u = u0 + (c >> 5), d0 = 4 * (c & 31);
+      for (int mb = 0; mb < M; mb += 4) {
+        V2Vec4<scalar_t> r[4];
+        int npv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = min(mb + i, M - 1);
+          npv[i] = (p.attn_seq_lens[m] + p.attn_part_size - 1) / p.attn_part_size;
+          const int64_t pb = ((int64_t)m * p.attn_heads + u) * p.attn_max_parts;
+          v2_vec4_load<scalar_t>(r[i], p.attn_exp_sums + pb, p.attn_max_logits + pb, reinterpret_cast<const scalar_t*>(p.attn_tmp) + pb * 128,
+                                 npv[i], 128, d0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (mb + i < M) *reinterpret_cast<u32x2*>(xl + (mb + i) * XS + (u - abase) * 256 + d0 * 2) = v2_vec4_math<scalar_t>(r[i], npv[i]);
+      }
+    }
+    __syncthreads();
+    if (u0 < u1) {
+      load_unit(u0, ua, false, true);
+      load_unit(u0 + 1, ub, false, true);
+    }
+  }
   if (u0 < u1) {
-    if constexpr (!NORM) {
+    if constexpr (!LDSA) {
       load_unit(u0, ua);
       load_unit(u0 + 1, ub);
     }
@@ -1833,14 +1882,42 @@ inline bool decode_norm_supported(int M, int N, int K, int num_groups, bool with
   return nt <= 256;
 }
 
-template <typename scalar_t, int MT, int NW, bool WS, bool NORM = false>
+// LDS bytes of the computed-A forms behind the reduction image (marlin_decode_kernel: rows of XS bytes + one zero row; ATTN: the
+// workgroup's K slice only + the waves' rescale scratch)
+inline size_t decode_lds_a_bytes(const GemmParams& p, int nw, bool norm, bool attn) {
+  if (norm) return (size_t)(p.M + 1) * (2 * p.K + 64);
+  if (attn) {
+    const int units = p.K / 128, workers = p.k_splits * nw, per = (units + workers - 1) / workers;
+    return (size_t)(p.M + 1) * (nw * per * 256 + 64);
+  }
+  return 0;
+}
+
+// Shapes the attention-reduce form (marlin_decode_kernel<ATTN>) serves: o_proj right behind paged_attention_v2's partition
+// launch - K = heads x 128 (one 128-k unit per head), at most 16 sequences, the decode kernel's 4-wave shape, LDS for the rows
+inline bool decode_attn_supported(int M, int N, int K, int num_groups, int heads, int head_size, int max_parts) {
+  // Rows served by default: NONE. With the reduce kernel on the same one-round-trip arithmetic (v2_vec4_*) the fused form is level
+  // with reduce launch + GEMM - decode step at batch 1 / 2 / 4: 2.171 / 2.318 / 2.393 ms fused, 2.177 / 2.315 / 2.370 unfused
+  // (gpurun_out/attn_fuse_ab.log); against the older wave-per-head reduce kernel it had been 2.5 % ahead at batch 1. NMX_GEMM_ATTN =
+  // rows to serve (at most 16) switches it on (tests, A/B).
+  int max_rows = 0;
+  if (const char* e = nmx_tune(NMX_TUNE_GEMM_ATTN)) max_rows = std::min(std::max(atoi(e), 0), 16);
+  if (M < 1 || M > max_rows || head_size != 128 || heads * 128 != K || K % 128 != 0 || N % 64 != 0 || max_parts < 1 || max_parts > 8) return false;
+  if (!(num_groups == 1 || (K / num_groups) % 128 == 0)) return false;
+  const DecodeCfg c = pick_decode_cfg(M, N, K);
+  if (c.nw != 4 || c.mt != 1) return false;
+  GemmParams q;
+  q.M = M; q.K = K; q.k_splits = c.splits; q.attn_max_parts = max_parts;
+  return (size_t)4 * 4096 + decode_lds_a_bytes(q, 4, false, true) <= 64 * 1024;
+}
+
+template <typename scalar_t, int MT, int NW, bool WS, bool NORM = false, bool ATTN = false>
 int launch_decode_cfg(const GemmParams& p, hipStream_t stream) {
-  // NORM: + the normalised rows and one zero row (marlin_decode_kernel: XS = 2 K + 64 bytes per row)
-  const size_t smem = (size_t)NW * MT * 4096 + (NORM ? (size_t)(p.M + 1) * (2 * p.K + 64) : 0);
+  const size_t smem = (size_t)NW * MT * 4096 + decode_lds_a_bytes(p, NW, NORM, ATTN);
   dim3 grid(p.act_out != nullptr ? p.N / 128 : p.N / 64, p.k_splits, ceil_div(p.M, 16 * MT));
 #define NMX_LAUNCH_DECODE(GROUPED_)                                                                                  \
   {                                                                                                                  \
-    auto kern = marlin_decode_kernel<scalar_t, MT, NW, GROUPED_, WS, NORM>;                                              \
+    auto kern = marlin_decode_kernel<scalar_t, MT, NW, GROUPED_, WS, NORM, ATTN>;                                            \
     if (smem > 64 * 1024)                                                                                            \
       NMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                   (int)smem));                                                                       \
@@ -1869,6 +1946,13 @@ int launch_decode(GemmParams& p, const DecodeCfg& cfg, void* scratch, int64_t sc
   const bool fuse = p.act_out != nullptr && p.k_splits == 1 && cfg.nw == 4 && cfg.mt == 1 && p.N % 128 == 0;
   void* const act_out = p.act_out;
   p.act_out = nullptr;  // the kernels below read it as "fused mode"
+  if (p.attn_tmp != nullptr) {
+    // attention-reduce A operand: the 4-wave shape (callers ask decode_attn_supported() first)
+    if (cfg.mt == 1 && cfg.nw == 4 && act_out == nullptr && (p.k_splits == 1 || p.defer_reduce) &&
+        (size_t)4 * 4096 + decode_lds_a_bytes(p, 4, false, true) <= 64 * 1024)
+      return ws ? launch_decode_cfg<scalar_t, 1, 4, true, false, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 4, false, false, true>(p, stream);
+    NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "attention-reduce gptq_marlin_gemm: shape not served (M = %d, N = %d, K = %d)", p.M, p.N, p.K);
+  }
   if (p.norm_partial != nullptr) {
     // norm-fused A operand: the two shapes the batch <= 4 decode step uses (callers ask decode_norm_supported() first)
     if constexpr (__is_same(scalar_t, f16)) {

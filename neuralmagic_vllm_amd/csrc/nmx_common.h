@@ -43,7 +43,7 @@ void nmx_set_error(const char* fmt, ...);
 enum NmxTune {
   NMX_TUNE_GEMM_CFG = 0, NMX_TUNE_GEMM_LEAN, NMX_TUNE_GEMM_LARGE, NMX_TUNE_GEMM_LARGE_NGRP, NMX_TUNE_GEMM_WIDE,
   NMX_TUNE_ATTN_NW, NMX_TUNE_PREFILL_GQ, NMX_TUNE_MM_NO_LDS, NMX_TUNE_MM_NT, NMX_TUNE_AWQ_NO_RING, NMX_TUNE_GPTQ_NO_RING,
-  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_SLAB_F32, NMX_TUNE_ATTN_PART, NMX_TUNE_GEMM_NORM_ROWS, NMX_TUNE_COUNT
+  NMX_TUNE_GPTQ_NT, NMX_TUNE_ATTN_FP8W, NMX_TUNE_MM_TILE, NMX_TUNE_GEMM_XCD_SPLIT, NMX_TUNE_GEMM_DMA, NMX_TUNE_SLAB_F32, NMX_TUNE_ATTN_PART, NMX_TUNE_GEMM_NORM_ROWS, NMX_TUNE_GEMM_ATTN, NMX_TUNE_COUNT
 };
 __attribute__((visibility("hidden"))) const char* nmx_tune(int id);  // value, or nullptr when unset
 
@@ -62,6 +62,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#include <float.h>
 #define NMX_WAVE 64
 
 // ---- scalar conversions (device) ------------------------------------------------------------------------
@@ -209,6 +210,157 @@ __device__ __forceinline__ void sum_partials8(const float* __restrict__ partial,
   for (int j = 0; j < 4; ++j) {
     e[j] = Scalar<T>::from_f32(a0[j]);
     e[4 + j] = Scalar<T>::from_f32(a1[j]);
+  }
+}
+
+
+// COHERENT: the partials were written by other workgroups of the SAME launch with write-through stores; they are read with
+// agent-scope (sc1) loads, which do not hit a stale line of this CU's L1 or this XCD's L2.
+template <bool COHERENT> __device__ __forceinline__ float ld_f32(const float* p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COHERENT, typename scalar_t> __device__ __forceinline__ scalar_t ld_elem(const scalar_t* p) {
+  if constexpr (COHERENT) {  // the aligned dword that holds the element
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint16_t h = (a & 2) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
+    return __builtin_bit_cast(scalar_t, h);
+  } else {
+    return *p;
+  }
+}
+
+// ---- the same reduce for at most 8 partitions, FOUR consecutive head dimensions of one (sequence, head) per lane, every load of a
+// lane issued before the first use (one memory round trip): marlin_decode_kernel<ATTN>'s prologue, where one wave has several heads
+// and rows to reduce and v2_reduce_head's wave-per-head form would walk them one after the other. Bit-identical to
+// v2_reduce_head: the same per-element expressions; the sum of the rescale factors in the order wave_reduce_sum gives partitions
+// sitting in lanes 0 .. 7 - ((r0 + r4) + (r2 + r6)) + ((r1 + r5) + (r3 + r7)) - and the maximum is order-free.
+template <typename scalar_t> struct V2Vec4 {
+  float ml[8], es[8];
+  u32x2 t[8];
+};
+template <typename scalar_t, bool COHERENT = false>
+__device__ __forceinline__ void v2_vec4_load(V2Vec4<scalar_t>& r, const float* __restrict__ exp_sums, const float* __restrict__ max_logits,
+                                             const scalar_t* __restrict__ tp, int np, int head_size, int d0) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int jj = min(j, max(np - 1, 0));
+    r.ml[j] = ld_f32<COHERENT>(max_logits + jj);
+    r.es[j] = ld_f32<COHERENT>(exp_sums + jj);
+    if constexpr (COHERENT)
+      r.t[j] = __builtin_bit_cast(u32x2, __hip_atomic_load(reinterpret_cast<const uint64_t*>(tp + (int64_t)jj * head_size + d0), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT));
+    else
+      r.t[j] = *reinterpret_cast<const u32x2*>(tp + (int64_t)jj * head_size + d0);
+  }
+}
+template <typename scalar_t>
+__device__ __forceinline__ u32x2 v2_vec4_math(const V2Vec4<scalar_t>& r, int np) {
+  if (np <= 1) return r.t[0];
+  float m = -FLT_MAX;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (j < np) m = fmaxf(m, r.ml[j]);
+  float resc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    resc[j] = (j < np) ? r.es[j] * __expf(r.ml[j] - m) : 0.f;
+    // a value of its own, as in v2_reduce_head (where it goes through LDS): without this hipcc contracts the product into the
+    // additions of the sum below (fma: one rounding less) and the last bit of the result can differ
+    asm volatile("" : "+v"(resc[j]));
+  }
+  const float gsum = ((resc[0] + resc[4]) + (resc[2] + resc[6])) + ((resc[1] + resc[5]) + (resc[3] + resc[7]));
+  const float inv = __fdividef(1.f, gsum + 1e-6f);
+  union { u32x2 u; scalar_t e[4]; } o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < np) {
+        union { u32x2 u; scalar_t e[4]; } v;
+        v.u = r.t[j];
+        acc += Scalar<scalar_t>::to_f32(v.e[i]) * resc[j] * inv;
+      }
+    }
+    o.e[i] = Scalar<scalar_t>::from_f32(acc);
+  }
+  return o.u;
+}
+
+// ---- v2 reduce of one (sequence, head) by ONE wave: follows attention_kernels.cu:567-669. Shared by the reduce kernel and by
+// the in-kernel reduce of the last-arriving partition (below), so the two forms write the same bits. resc: np floats of LDS. ----
+template <typename scalar_t, bool COHERENT = false>
+__device__ __forceinline__ void v2_reduce_head(scalar_t* __restrict__ o, const float* __restrict__ exp_sums,
+                                               const float* __restrict__ max_logits, const scalar_t* __restrict__ tp, int np,
+                                               int head_size, float* __restrict__ absmax_dst, float* resc, int lane) {
+  float amax = 0.f;
+  {
+    // at most 8 partitions (every fine-partition launch, and 512-token partitions up to 4,096 tokens): the four-dimensions-per-lane
+    // form, all loads of a lane in one round trip - the SAME function marlin_decode_kernel<ATTN> runs in its prologue, so the reduce
+    // launch and the fused form agree bit for bit by construction
+    if (sizeof(scalar_t) == 2 && np <= 8 && head_size % 4 == 0) {  // (16-bit outputs: four of them are the lane's 8 bytes)
+      for (int c = lane; c < head_size / 4; c += 64) {
+        V2Vec4<scalar_t> r;
+        v2_vec4_load<scalar_t, COHERENT>(r, exp_sums, max_logits, tp, np, head_size, 4 * c);
+        union { u32x2 u; scalar_t e[4]; } ov;
+        ov.u = v2_vec4_math<scalar_t>(r, np);
+        *reinterpret_cast<u32x2*>(o + 4 * c) = ov.u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(ov.e[i])));
+      }
+      if (absmax_dst != nullptr) {
+        amax = wave_reduce_max(amax);
+        if (lane == 0) *absmax_dst = amax;
+      }
+      return;
+    }
+  }
+  if (np <= 1) {
+    for (int i = lane; i < head_size; i += 64) {
+      const scalar_t v = ld_elem<COHERENT>(tp + i);
+      o[i] = v;
+      amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(v)));
+    }
+    if (absmax_dst != nullptr) {
+      amax = wave_reduce_max(amax);
+      if (lane == 0) *absmax_dst = amax;
+    }
+    return;
+  }
+  float m = -FLT_MAX;
+  for (int i = lane; i < np; i += 64) m = fmaxf(m, ld_f32<COHERENT>(max_logits + i));
+  m = wave_reduce_max(m);
+  float gsum = 0.f;
+  for (int i = lane; i < np; i += 64) {
+    const float r = ld_f32<COHERENT>(exp_sums + i) * __expf(ld_f32<COHERENT>(max_logits + i) - m);
+    resc[i] = r;
+    gsum += r;
+  }
+  gsum = wave_reduce_sum(gsum);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes before its reads (one wave: no s_barrier)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float inv = __fdividef(1.f, gsum + 1e-6f);
+  for (int d = lane; d < head_size; d += 64) {
+    float acc = 0.f;
+    // (the partitions' values in batches of 8 loads issued back to back - with one load per iteration every partition cost a
+    //  memory round trip; the additions keep the order j = 0, 1, ...)
+    for (int j0 = 0; j0 < np; j0 += 8) {
+      scalar_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ld_elem<COHERENT>(tp + (int64_t)min(j0 + i, np - 1) * head_size + d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (j0 + i < np) acc += Scalar<scalar_t>::to_f32(v[i]) * resc[j0 + i] * inv;
+    }
+    const scalar_t ov = Scalar<scalar_t>::from_f32(acc);
+    o[d] = ov;
+    amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(ov)));
+  }
+  if (absmax_dst != nullptr) {
+    amax = wave_reduce_max(amax);
+    if (lane == 0) *absmax_dst = amax;
   }
 }
 

@@ -22,7 +22,7 @@ namespace {
 const char* const kTuneNames[NMX_TUNE_COUNT] = {
     "NMX_GEMM_CFG", "NMX_GEMM_LEAN", "NMX_GEMM_LARGE", "NMX_GEMM_LARGE_NGRP", "NMX_GEMM_WIDE", "NMX_ATTN_NW",
     "NMX_PREFILL_GQ", "NMX_MM_NO_LDS", "NMX_MM_NT", "NMX_AWQ_NO_RING", "NMX_GPTQ_NO_RING", "NMX_GPTQ_NT", "NMX_ATTN_FP8W", "NMX_MM_TILE",
-    "NMX_GEMM_XCD_SPLIT", "NMX_GEMM_DMA", "NMX_SLAB_F32", "NMX_ATTN_PART", "NMX_GEMM_NORM_ROWS"};
+    "NMX_GEMM_XCD_SPLIT", "NMX_GEMM_DMA", "NMX_SLAB_F32", "NMX_ATTN_PART", "NMX_GEMM_NORM_ROWS", "NMX_GEMM_ATTN"};
 struct TuneTable {
   char value[NMX_TUNE_COUNT][64];
   bool set[NMX_TUNE_COUNT];

@@ -154,77 +154,8 @@ __device__ __forceinline__ u32x4 p_to_operand(u32x2 a, u32x2 b) {
 }
 
 
-// ---- v2 reduce of one (sequence, head) by ONE wave: follows attention_kernels.cu:567-669. Shared by the reduce kernel and by
-// the in-kernel reduce of the last-arriving partition (below), so the two forms write the same bits. resc: np floats of LDS. ----
-// COHERENT: the partials were written by other workgroups of the SAME launch with write-through stores; they are read with
-// agent-scope (sc1) loads, which do not hit a stale line of this CU's L1 or this XCD's L2.
-template <bool COHERENT> __device__ __forceinline__ float ld_f32(const float* p) {
-  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-template <bool COHERENT, typename scalar_t> __device__ __forceinline__ scalar_t ld_elem(const scalar_t* p) {
-  if constexpr (COHERENT) {  // the aligned dword that holds the element
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint16_t h = (a & 2) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
-    return __builtin_bit_cast(scalar_t, h);
-  } else {
-    return *p;
-  }
-}
-
-template <typename scalar_t, bool COHERENT = false>
-__device__ __forceinline__ void v2_reduce_head(scalar_t* __restrict__ o, const float* __restrict__ exp_sums,
-                                               const float* __restrict__ max_logits, const scalar_t* __restrict__ tp, int np,
-                                               int head_size, float* __restrict__ absmax_dst, float* resc, int lane) {
-  float amax = 0.f;
-  if (np <= 1) {
-    for (int i = lane; i < head_size; i += 64) {
-      const scalar_t v = ld_elem<COHERENT>(tp + i);
-      o[i] = v;
-      amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(v)));
-    }
-    if (absmax_dst != nullptr) {
-      amax = wave_reduce_max(amax);
-      if (lane == 0) *absmax_dst = amax;
-    }
-    return;
-  }
-  float m = -FLT_MAX;
-  for (int i = lane; i < np; i += 64) m = fmaxf(m, ld_f32<COHERENT>(max_logits + i));
-  m = wave_reduce_max(m);
-  float gsum = 0.f;
-  for (int i = lane; i < np; i += 64) {
-    const float r = ld_f32<COHERENT>(exp_sums + i) * __expf(ld_f32<COHERENT>(max_logits + i) - m);
-    resc[i] = r;
-    gsum += r;
-  }
-  gsum = wave_reduce_sum(gsum);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes before its reads (one wave: no s_barrier)
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const float inv = __fdividef(1.f, gsum + 1e-6f);
-  for (int d = lane; d < head_size; d += 64) {
-    float acc = 0.f;
-    // (the partitions' values in batches of 8 loads issued back to back - with one load per iteration every partition cost a
-    //  memory round trip; the additions keep the order j = 0, 1, ...)
-    for (int j0 = 0; j0 < np; j0 += 8) {
-      scalar_t v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = ld_elem<COHERENT>(tp + (int64_t)min(j0 + i, np - 1) * head_size + d);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (j0 + i < np) acc += Scalar<scalar_t>::to_f32(v[i]) * resc[j0 + i] * inv;
-    }
-    const scalar_t ov = Scalar<scalar_t>::from_f32(acc);
-    o[d] = ov;
-    amax = fmaxf(amax, fabsf(Scalar<scalar_t>::to_f32(ov)));
-  }
-  if (absmax_dst != nullptr) {
-    amax = wave_reduce_max(amax);
-    if (lane == 0) *absmax_dst = amax;
-  }
-}
+// (v2_reduce_head - the reduce of one (sequence, head) by one wave - lives in nmx_common.h: the reduce kernel, the in-kernel
+// reduce below and marlin_decode_kernel's attention-reduce prologue share it)
 
 // ---- v2 without a reduce launch (round 3, late): every partition workgroup of a (sequence, kv head, q tile) publishes its
 // partial results, then takes a ticket on that group's counter; the LAST one to arrive reduces the group's heads (one wave per
@@ -1136,7 +1067,7 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
                   float scale, const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
                   int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale, int tp_rank,
                   int bs_local_blocks, int bs_vert_stride, int bs_block_size, int bs_head_sliding_step,
-                  hipStream_t stream, int part_size = kPartitionSize, int* counters = nullptr) {
+                  hipStream_t stream, int part_size = kPartitionSize, int* counters = nullptr, bool skip_reduce = false) {
   NMX_CHECK(part_size >= 64 && part_size <= kPartitionSize && part_size % 64 == 0, NMX_ERR_INVALID_ARG,
             "paged_attention: partition size %d (64 .. 512, a multiple of 64)", part_size);
   NMX_CHECK(block_size == 8 || block_size == 16 || block_size == 32, NMX_ERR_UNSUPPORTED,
@@ -1196,7 +1127,7 @@ int run_attention(bool partitioned, void* out, float* absmax, float* exp_sums, f
   if (dtype == NMX_F32) rc = launch_attn_f32(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
   else if (dtype == NMX_F16) rc = dispatch_kv<f16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
   else rc = dispatch_kv<bf16>(p, kv_dtype, head_size, num_seqs, num_partitions, stream);
-  if (rc != NMX_OK || !partitioned || p.counters != nullptr) return rc;
+  if (rc != NMX_OK || !partitioned || p.counters != nullptr || skip_reduce) return rc;
 
   dim3 rgrid(num_heads, num_seqs);
   const size_t rsmem = (size_t)num_partitions * sizeof(float);
@@ -1338,4 +1269,46 @@ extern "C" int nmx_paged_attention_v2_ps(void* out, float* absmax, float* exp_su
 extern "C" int64_t nmx_paged_attention_counters_numel(int num_seqs, int num_heads, int num_kv_heads) {
   if (num_seqs <= 0 || num_heads <= 0 || num_kv_heads <= 0) return 0;
   return (int64_t)num_seqs * num_kv_heads * ((num_heads / num_kv_heads + 15) / 16);
+}
+
+// ---- v2 in two halves (round 3, late): the partition launch alone, and the reduce as an op of its own. A caller that feeds the
+// attention output straight into a GPTQ-Marlin o_proj hands the partition results to nmx_gptq_marlin_gemm_attn instead (the GEMM
+// reduces them in its prologue: one launch less); nmx_paged_attention_v2_reduce is the fallback for every other consumer.
+extern "C" int nmx_paged_attention_v2_partials(float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+                                               const void* key_cache, const void* value_cache, int num_seqs, int num_heads,
+                                               int num_kv_heads, int head_size, int block_size, int64_t q_stride,
+                                               int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                                               const int32_t* block_tables, int max_num_blocks_per_seq, const int32_t* seq_lens,
+                                               int max_seq_len, const float* alibi_slopes, int dtype, int kv_dtype, float kv_scale,
+                                               int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
+                                               int bs_head_sliding_step, int partition_size, nmx_stream_t stream) {
+  return run_attention(true, tmp_out /* unused */, nullptr, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
+                       num_heads, num_kv_heads, head_size, block_size, q_stride, kv_block_stride, kv_head_stride, scale, block_tables,
+                       max_num_blocks_per_seq, seq_lens, max_seq_len, alibi_slopes, dtype, kv_dtype, kv_scale, tp_rank,
+                       bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step, (hipStream_t)stream, partition_size,
+                       nullptr, true);
+}
+
+extern "C" int nmx_paged_attention_v2_reduce(void* out, const float* exp_sums, const float* max_logits, const void* tmp_out,
+                                             const int32_t* seq_lens, int num_seqs, int num_heads, int head_size,
+                                             int max_num_partitions, int partition_size, int dtype, nmx_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (num_seqs == 0) return NMX_OK;
+  NMX_CHECK(partition_size >= 64 && partition_size % 64 == 0 && max_num_partitions >= 1, NMX_ERR_INVALID_ARG,
+            "paged_attention_v2_reduce: partition size %d / partitions %d", partition_size, max_num_partitions);
+  dim3 rgrid(num_heads, num_seqs);
+  const size_t rsmem = (size_t)max_num_partitions * sizeof(float);
+  if (dtype == NMX_F32)
+    paged_attention_v2_reduce_kernel<float><<<rgrid, 64, rsmem, stream>>>((float*)out, exp_sums, max_logits, (const float*)tmp_out, seq_lens,
+                                                                          max_num_partitions, head_size, nullptr, partition_size);
+  else if (dtype == NMX_F16)
+    paged_attention_v2_reduce_kernel<f16><<<rgrid, 64, rsmem, stream>>>((f16*)out, exp_sums, max_logits, (const f16*)tmp_out, seq_lens,
+                                                                        max_num_partitions, head_size, nullptr, partition_size);
+  else if (dtype == NMX_BF16)
+    paged_attention_v2_reduce_kernel<bf16><<<rgrid, 64, rsmem, stream>>>((bf16*)out, exp_sums, max_logits, (const bf16*)tmp_out, seq_lens,
+                                                                         max_num_partitions, head_size, nullptr, partition_size);
+  else
+    NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "paged_attention_v2_reduce: unsupported dtype code %d", dtype);
+  NMX_LAUNCH_CHECK();
+  return NMX_OK;
 }
