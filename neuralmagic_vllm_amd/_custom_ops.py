@@ -760,7 +760,7 @@ def fused_add_rms_norm_gptq_marlin_gemm(g: DeferredGemm, residual: torch.Tensor,
         _p(g.partial), c_int(g.coded), _p(residual), _p(res_out), _p(norm_weight), c_f(epsilon), _p(b_q_weight), _p(b_scales), _p(c),
         _p(act), c_i64(workspace.numel()), _p(scratch), c_i64(scratch.numel()), c_int(size_m), c_int(size_n), c_int(size_k),
         c_int(num_bits), c_int(b_scales.shape[0]), c_int(_dt(residual)), ctypes.byref(splits), _stream(residual)))
-    g.splits = 1  # consumed (g.out was not written: the sum only ever existed inside the GEMM's prologue)
+    g.splits, g.out, g.partial = 1, None, None  # consumed: the reduced tensor never existed (a later materialize() returns None, loudly useless)
     if silu_and_mul:
         return act, res_out
     if (splits.value & 0xff) > 1:
