@@ -426,3 +426,37 @@ def test_attn_reduce_gemm(ops, tune, num_seqs, dtype, kv_dtype, rows):
     parts3 = ops.paged_attention_v2_partials(q, kc, vc, nkv, scale, bt, sl, block_size, max_len, None, kv_dtype, kv_scale)
     got3 = ops.paged_attention_gptq_marlin_gemm(parts3, qw, sw.to(dtype), e, e, wsp, 4, num_seqs, H, H, True)
     assert parts3.out is not None and torch.equal(_bits(got3.materialize()), _bits(want))
+
+
+@pytest.mark.parametrize("consumer", ["qkv", "gate_up_act"])
+@pytest.mark.parametrize("kind", ["channelwise", "not_ws"])
+def test_norm_fused_gemm_variants(ops, tune, consumer, kind):
+    """The other instantiations of marlin_decode_kernel<NORM> at one row: channel-wise scales (one scale row: GROUPED = false) and
+    group scales applied to the fp32 group accumulators instead of the weights (NMX_GEMM_LEAN ws = 0: WS = false); bit-identical to
+    the two-launch sequence under the same configuration."""
+    seed_all(11)
+    M, H, Kp = 1, 4096, 4096
+    qp, sp = _weights(Kp, H, 3)
+    a = torch.randn(M, Kp, dtype=torch.float16, device=DEV)
+    N = {"qkv": 6144, "gate_up_act": 28672}[consumer]
+    act = consumer == "gate_up_act"
+    qc, sc = _weights(H, N, 4)
+    if kind == "channelwise":
+        sc = sc[:1].contiguous()
+    e = torch.empty(0, dtype=torch.int32, device=DEV)
+    wsp = torch.zeros(max(N, H) // 64 * 16, dtype=torch.int32, device=DEV)
+    res0 = torch.randn(M, H, dtype=torch.float16, device=DEV)
+    w = (torch.rand(H, device=DEV) + 0.5).half()
+    g1 = ops.gptq_marlin_gemm_deferred(a, qp, sp, e, e, wsp, 4, M, H, Kp, True)  # the producers under the default dispatch
+    g2 = ops.gptq_marlin_gemm_deferred(a, qp, sp, e, e, wsp, 4, M, H, Kp, True)
+    assert g1.splits > 1 and g2.splits > 1
+    if kind == "not_ws":
+        tune(NMX_GEMM_LEAN="4,2,1,0" if not act else "4,1,1,0")
+    res_a = res0.clone()
+    h = ops.fused_add_rms_norm_splitk(g1, res_a, w, 1e-5).clone()
+    want = (ops.gptq_marlin_gemm_silu_and_mul if act else ops.gptq_marlin_gemm)(h, qc, sc, e, e, wsp, 4, M, N, H, True)
+    got, res_new = ops.fused_add_rms_norm_gptq_marlin_gemm(g2, res0.clone(), w, 1e-5, qc, sc, e, e, wsp, 4, M, N, H, True, silu_and_mul=act)
+    torch.cuda.synchronize()
+    assert res_new.data_ptr() != res_a.data_ptr() and torch.equal(_bits(res_new), _bits(res_a))
+    out = got if act else got.materialize()
+    assert torch.equal(_bits(out), _bits(want))
