@@ -236,7 +236,7 @@ int nmx_gptq_marlin_gemm_silu_and_mul(const void* a, const int32_t* b_q_weight, 
  * computed in the prologue of every workgroup, then gptq_marlin_gemm on A: act_out == NULL leaves c or K-split slabs and
  * *splits_out as nmx_gptq_marlin_gemm_deferred does, act_out != NULL writes silu_and_mul of the result as
  * nmx_gptq_marlin_gemm_silu_and_mul does. norm_splits: slab count (>= 2) | NMX_SPLITK_F16. Bit-identical to the unfused
- * sequence. nmx_gptq_marlin_gemm_norm_supported() says which shapes are served (fp16, 4 bits, no act-order, size_m <= 4,
+ * sequence. nmx_gptq_marlin_gemm_norm_supported() says which shapes are served (fp16 / bf16, 4 bits, no act-order, one row by default,
  * the decode kernel's shapes); others return NMX_ERR_UNSUPPORTED. */
 int nmx_gptq_marlin_gemm_norm_supported(int size_m, int size_n, int size_k, int num_groups, int num_bits, int dtype,
                                         int with_act);

@@ -734,13 +734,13 @@ def fused_add_rms_norm_gptq_marlin_gemm(g: DeferredGemm, residual: torch.Tensor,
     post_attention_layernorm + gate_up_proj + act, or the next layer's input_layernorm + qkv_proj (models/llama.py:205-230).
     Returns (result, residual): result is the DeferredGemm of gptq_marlin_gemm_deferred (silu_and_mul=False) or the activation
     tensor [size_m, size_n / 2]; residual is the tensor that now holds the updated residual stream.
-    At batch <= 4 (fp16, int4 without act-order, the decode kernel's shapes: nmx_gptq_marlin_gemm_norm_supported) this is ONE
+    At ONE row by default (fp16 / bf16, int4 without act-order, the decode kernel's shapes: nmx_gptq_marlin_gemm_norm_supported) this is ONE
     launch - every workgroup of the GEMM computes the norm in its prologue while its first weight loads are in flight, and the
     residual goes to a NEW tensor; otherwise the two ops run one after the other and the residual is updated in place. The
     results are bit-identical either way (tests/test_fused_gpu.py)."""
     _dev(residual)
     has_idx = g_idx is not None and g_idx.numel() > 0
-    fused = (g.splits >= 2 and g.sa is None and not has_idx and residual.dtype == torch.float16 and residual.is_contiguous()
+    fused = (g.splits >= 2 and g.sa is None and not has_idx and residual.dtype in (torch.float16, torch.bfloat16) and residual.is_contiguous()
              and tuple(residual.shape) == (size_m, size_k) and _lib.lib().nmx_gptq_marlin_gemm_norm_supported(
                  c_int(size_m), c_int(size_n), c_int(size_k), c_int(b_scales.shape[0]), c_int(num_bits), c_int(_dt(residual)),
                  c_int(int(silu_and_mul))))

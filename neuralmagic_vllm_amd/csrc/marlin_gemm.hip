@@ -51,9 +51,9 @@ int marlin_common(const void* a, const int32_t* b_q_weight, const void* b_scales
   if (num_groups > 1 && !p.slow_act_order)
     NMX_CHECK(p.group_size % 32 == 0, NMX_ERR_UNSUPPORTED, "group_size = %d must be a multiple of 32", p.group_size);
   NMX_CHECK(norm == nullptr || norm->attn_tmp != nullptr ||
-                (kind == W_INT4 && !has_act_order && dtype == NMX_F16 &&
+                (kind == W_INT4 && !has_act_order &&
                  decode_norm_supported(size_m, size_n, size_k, num_groups, act_out != nullptr)),
-            NMX_ERR_UNSUPPORTED, "norm-fused gptq_marlin_gemm: fp16, int4 without act-order, shapes of nmx_gptq_marlin_gemm_norm_supported");
+            NMX_ERR_UNSUPPORTED, "norm-fused gptq_marlin_gemm: int4 without act-order, shapes of nmx_gptq_marlin_gemm_norm_supported");
   NMX_CHECK(norm == nullptr || norm->attn_tmp == nullptr ||
                 (kind == W_INT4 && !has_act_order && act_out == nullptr &&
                  decode_attn_supported(size_m, size_n, size_k, num_groups, norm->attn_heads, 128, norm->attn_max_parts)),
@@ -209,7 +209,7 @@ extern "C" int nmx_fp8_marlin_gemm(const void* a, const int32_t* b_q_weight, con
 // unfused sequence. Ask nmx_gptq_marlin_gemm_norm_supported() first: other shapes return NMX_ERR_UNSUPPORTED.
 extern "C" int nmx_gptq_marlin_gemm_norm_supported(int size_m, int size_n, int size_k, int num_groups, int num_bits, int dtype,
                                                    int with_act) {
-  return num_bits == 4 && dtype == NMX_F16 && decode_norm_supported(size_m, size_n, size_k, num_groups, with_act != 0) ? 1 : 0;
+  return num_bits == 4 && (dtype == NMX_F16 || dtype == NMX_BF16) && decode_norm_supported(size_m, size_n, size_k, num_groups, with_act != 0) ? 1 : 0;
 }
 
 extern "C" int nmx_gptq_marlin_gemm_norm(const float* norm_partial, int norm_splits, const void* residual_in, void* residual_out,

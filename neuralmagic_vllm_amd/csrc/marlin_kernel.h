@@ -1862,7 +1862,7 @@ inline DecodeCfg pick_decode_cfg(int M, int N, int K) {
   return c;
 }
 
-// Shapes the norm-fused form (marlin_decode_kernel<NORM>) serves: fp16, plain int4 layout (the caller knows), at most
+// Shapes the norm-fused form (marlin_decode_kernel<NORM>) serves: fp16 / bf16, plain int4 layout (the caller knows), at most
 // kNormMaxRows rows, the decode kernel's 4-wave shape (with_act: its unsplit gate | up form), and a hidden size whose
 // rms_norm_splitk_kernel thread count fits the workgroup (bit identity with the unfused sequence)
 inline bool decode_norm_supported(int M, int N, int K, int num_groups, bool with_act) {
@@ -1955,16 +1955,14 @@ int launch_decode(GemmParams& p, const DecodeCfg& cfg, void* scratch, int64_t sc
   }
   if (p.norm_partial != nullptr) {
     // norm-fused A operand: the two shapes the batch <= 4 decode step uses (callers ask decode_norm_supported() first)
-    if constexpr (__is_same(scalar_t, f16)) {
-      if (fuse) {
-        p.act_out = act_out;
-        rc = ws ? launch_decode_cfg<scalar_t, 1, 8, true, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 8, false, true>(p, stream);
-        p.act_done = 1;
-        return rc;
-      }
-      if (cfg.mt == 1 && cfg.nw == 4 && act_out == nullptr && (p.k_splits == 1 || p.defer_reduce))
-        return ws ? launch_decode_cfg<scalar_t, 1, 4, true, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 4, false, true>(p, stream);
+    if (fuse) {
+      p.act_out = act_out;
+      rc = ws ? launch_decode_cfg<scalar_t, 1, 8, true, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 8, false, true>(p, stream);
+      p.act_done = 1;
+      return rc;
     }
+    if (cfg.mt == 1 && cfg.nw == 4 && act_out == nullptr && (p.k_splits == 1 || p.defer_reduce))
+      return ws ? launch_decode_cfg<scalar_t, 1, 4, true, true>(p, stream) : launch_decode_cfg<scalar_t, 1, 4, false, true>(p, stream);
     NMX_CHECK(false, NMX_ERR_UNSUPPORTED, "norm-fused gptq_marlin_gemm: shape not served (M = %d, N = %d, K = %d)", p.M, p.N, p.K);
   }
   if (fuse) {

@@ -429,24 +429,27 @@ def test_attn_reduce_gemm(ops, tune, num_seqs, dtype, kv_dtype, rows):
 
 
 @pytest.mark.parametrize("consumer", ["qkv", "gate_up_act"])
-@pytest.mark.parametrize("kind", ["channelwise", "not_ws"])
+@pytest.mark.parametrize("kind", ["channelwise", "not_ws", "bf16"])
 def test_norm_fused_gemm_variants(ops, tune, consumer, kind):
     """The other instantiations of marlin_decode_kernel<NORM> at one row: channel-wise scales (one scale row: GROUPED = false) and
     group scales applied to the fp32 group accumulators instead of the weights (NMX_GEMM_LEAN ws = 0: WS = false); bit-identical to
-    the two-launch sequence under the same configuration."""
+    the two-launch sequence under the same configuration; and bfloat16 activations / scales / norm weight."""
     seed_all(11)
+    dt = torch.bfloat16 if kind == "bf16" else torch.float16
     M, H, Kp = 1, 4096, 4096
     qp, sp = _weights(Kp, H, 3)
-    a = torch.randn(M, Kp, dtype=torch.float16, device=DEV)
+    sp = sp.to(dt)
+    a = torch.randn(M, Kp, dtype=dt, device=DEV)
     N = {"qkv": 6144, "gate_up_act": 28672}[consumer]
     act = consumer == "gate_up_act"
     qc, sc = _weights(H, N, 4)
+    sc = sc.to(dt)
     if kind == "channelwise":
         sc = sc[:1].contiguous()
     e = torch.empty(0, dtype=torch.int32, device=DEV)
     wsp = torch.zeros(max(N, H) // 64 * 16, dtype=torch.int32, device=DEV)
-    res0 = torch.randn(M, H, dtype=torch.float16, device=DEV)
-    w = (torch.rand(H, device=DEV) + 0.5).half()
+    res0 = torch.randn(M, H, dtype=dt, device=DEV)
+    w = (torch.rand(H, device=DEV) + 0.5).to(dt)
     g1 = ops.gptq_marlin_gemm_deferred(a, qp, sp, e, e, wsp, 4, M, H, Kp, True)  # the producers under the default dispatch
     g2 = ops.gptq_marlin_gemm_deferred(a, qp, sp, e, e, wsp, 4, M, H, Kp, True)
     assert g1.splits > 1 and g2.splits > 1
