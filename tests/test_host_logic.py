@@ -143,3 +143,27 @@ def test_split_plan_of_the_llama_shapes_is_stable():
     # batch 256 (the bench default): int4 / sparse qkv, o, gate_up, down and the fp8 tile kernel's plan
     assert [splits(gm, 256, n, k) for n, k in ((6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336))] == [2, 4, 0, 8]
     assert [splits(mm, 256, n, k) for n, k in ((6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336))] == [2, 4, 0, 8]
+
+
+def test_small_batch_host_rules():
+    """Host-only rules added in round 3's second session (no GPU): the partition size paged_attention_v2 runs with, the shapes the
+    norm-fused / attention-reduce GEMM forms serve by default, the counter buffer size."""
+    import ctypes
+
+    from neuralmagic_vllm_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.nmx_paged_attention_counters_numel.restype = ctypes.c_int64
+    ps = lib.nmx_paged_attention_partition_size
+    # Llama-3-8B heads (32 / 8): finer partitions while one round of workgroups holds them, >= 128 tokens, <= 8 partitions per sequence
+    assert [ps(b, 32, 8, 1024) for b in (1, 4, 8, 16, 32, 256)] == [128, 128, 256, 512, 512, 512]
+    assert [ps(1, 32, 8, c) for c in (128, 512, 2048, 4096, 8192, 32768)] == [128, 128, 256, 512, 512, 512]
+    assert ps(1, 40, 2, 1024) == 128 and ps(0, 32, 8, 1024) == 512 and ps(2, 12, 12, 1024) == 128
+    assert lib.nmx_paged_attention_counters_numel(4, 32, 8) == 32 and lib.nmx_paged_attention_counters_numel(3, 40, 2) == 12
+    norm = lib.nmx_gptq_marlin_gemm_norm_supported  # (m, n, k, groups, bits, dtype, with_act)
+    assert norm(1, 6144, 4096, 32, 4, 1, 0) == 1 and norm(1, 28672, 4096, 32, 4, 1, 1) == 1 and norm(1, 6144, 4096, 32, 4, 2, 0) == 1
+    assert norm(2, 6144, 4096, 32, 4, 1, 0) == 0            # one row by default
+    assert norm(1, 6144, 4096, 32, 8, 1, 0) == 0            # 4 bits only
+    assert norm(1, 4096, 14336, 112, 4, 1, 0) == 0          # long K is not on the decode kernel
+    assert norm(1, 1280, 8192, 64, 4, 1, 0) == 0            # hidden 8192: the norm kernel's 512 threads do not fit the 4-wave shape
+    attn = lib.nmx_gptq_marlin_gemm_attn_supported  # (m, n, k, groups, bits, dtype, heads, head_size, max_parts)
+    assert attn(1, 4096, 4096, 32, 4, 1, 32, 128, 8) == 0   # off by default (level with the reduce launch)
