@@ -309,9 +309,9 @@ __global__ void rms_norm_splitk_kernel(T* __restrict__ out, const float* __restr
   for (int k = 0; k < VPT; ++k) {
     const int v = threadIdx.x + k * blockDim.x;
     if (v < nvec) {
-      sum_partials8<T>(partial, splits, slab, row + v * 8, x[k].e, sa, sb);
-      V r;
+      V r;  // requested BEFORE the slab sum consumes its loads: one memory round trip instead of two
       r.u = *reinterpret_cast<const u32x4*>(residual + row + v * 8);
+      sum_partials8<T>(partial, splits, slab, row + v * 8, x[k].e, sa, sb);
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[k].e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(x[k].e[j]) + Scalar<T>::to_f32(r.e[j]));
       *reinterpret_cast<u32x4*>(residual + row + v * 8) = x[k].u;
@@ -388,7 +388,12 @@ __global__ void rope_cache_kernel(const int64_t* __restrict__ positions, T* __re
   for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < heads * vper; i += blockDim.x * gridDim.y) {
     const int head = i / vper, ro = (i % vper) * 8;
     const int64_t base = row + (int64_t)head * head_size;
-    V x, y;
+    V x, y, c, sn;
+    const bool is_v = head >= num_heads + num_kv_heads;
+    if (!is_v) {  // cos / sin requested BEFORE the slab sums consume their loads (a dependent round trip less)
+      c.u = *reinterpret_cast<const u32x4*>(cache + ro);
+      sn.u = *reinterpret_cast<const u32x4*>(cache + embed + ro);
+    }
     if (splits > 1) {
       sum_partials8<T>(partial, splits, slab, base + ro, x.e, sa, sb);
       sum_partials8<T>(partial, splits, slab, base + embed + ro, y.e, sa, sb);
@@ -396,11 +401,8 @@ __global__ void rope_cache_kernel(const int64_t* __restrict__ positions, T* __re
       x.u = *reinterpret_cast<const u32x4*>(qkv + base + ro);
       y.u = *reinterpret_cast<const u32x4*>(qkv + base + embed + ro);
     }
-    const bool is_v = head >= num_heads + num_kv_heads;
     if (!is_v) {
-      V c, sn, ox, oy;
-      c.u = *reinterpret_cast<const u32x4*>(cache + ro);
-      sn.u = *reinterpret_cast<const u32x4*>(cache + embed + ro);
+      V ox, oy;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         ox.e[j] = Scalar<T>::from_f32(Scalar<T>::to_f32(rnd_mul<T>(x.e[j], c.e[j])) - Scalar<T>::to_f32(rnd_mul<T>(y.e[j], sn.e[j])));

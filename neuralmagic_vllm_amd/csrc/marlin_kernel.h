@@ -1403,9 +1403,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16) ? 4 : 2) void marlin_decode_ker
       for (int k = 0; k < 2; ++k) {
         const int v = tid + k * NT;
         if (tid < NT && v < nvec) {
-          sum_partials8<scalar_t>(p.norm_partial, p.norm_splits, slab, (int64_t)m * K + v * 8, x[k].e);
-          V r;
+          V r;  // (requested before the slab sum consumes its loads)
           r.u = *reinterpret_cast<const u32x4*>(res_in + (int64_t)m * K + v * 8);
+          sum_partials8<scalar_t>(p.norm_partial, p.norm_splits, slab, (int64_t)m * K + v * 8, x[k].e);
 #pragma unroll
           for (int j = 0; j < 8; ++j) x[k].e[j] = Scalar<scalar_t>::from_f32(Scalar<scalar_t>::to_f32(x[k].e[j]) + Scalar<scalar_t>::to_f32(r.e[j]));
         }
